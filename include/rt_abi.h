@@ -1,0 +1,269 @@
+/*
+ * rt_abi.h — C ABI of libraytracer_amd.so, the MI355X (gfx950) replacement for the
+ * Vulkan compute pipeline of VictorOrrios/Raytracer.
+ *
+ * The reference has no plugin/FFI layer: its "interface" is the Vulkan binding contract
+ * of shaders/raytracer.comp as driven by RaytracingApp in src/main.cpp.  Every entry
+ * point below cites the reference code it replaces (paths relative to the reference
+ * repository root).  All functions return RT_OK (0) or a negative RtStatus; nothing
+ * throws across this boundary.  One context owns one HIP stream on one device; calls on
+ * a context are not thread-safe, different contexts may be driven from different threads.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_HIP = -2,            /* a HIP runtime call failed; see rt_last_error()            */
+    RT_ERR_NO_SCENE = -3,       /* render requested before rt_upload_scene                    */
+    RT_ERR_NO_FRAMEBUFFER = -4, /* render requested before rt_resize / rt_bind_framebuffer    */
+    RT_ERR_UNSUPPORTED = -5,    /* e.g. POINT/CONE/AREA lights: undefined in the reference    */
+    RT_ERR_IO = -6,             /* asset file missing / malformed                             */
+    RT_ERR_TOO_LARGE = -7
+} RtStatus;
+
+/* ------------------------------------------------------------------ scene element layouts
+ * std430 layouts of the shader's SSBO element types (shaders/raytracer.comp:47-106) and
+ * of their host mirrors (src/definitions.hpp:18-87).  Sizes/offsets are static_asserted
+ * in raytracer_amd/csrc/rt_layout_check.cpp. */
+
+/* light types: shaders/raytracer.comp:16-22, src/definitions.hpp:7-15 */
+enum { RT_LIGHT_AMBIENT = 0, RT_LIGHT_SPHERE = 1, RT_LIGHT_POINT = 2, RT_LIGHT_DIRECTIONAL = 3,
+       RT_LIGHT_CONE = 4, RT_LIGHT_AREA = 5, RT_LIGHT_TRIANGLE = 6 };
+
+typedef struct RtSphere {   /* 32 B: raytracer.comp:84-88, definitions.hpp:18-22 */
+    float   pos[3];
+    float   r;
+    int32_t mat;
+    int32_t _pad[3];
+} RtSphere;
+
+typedef struct RtTriangle { /* 64 B: raytracer.comp:90-96, definitions.hpp:24-30 */
+    float   v0[3];  float _p0;
+    float   v1[3];  float _p1;
+    float   v2[3];  float _p2;
+    float   normal[3];
+    int32_t mat;
+} RtTriangle;
+
+typedef struct RtVertex {   /* 16 B: raytracer.comp:104-106, definitions.hpp:40-42 */
+    float pos[3];
+    float _pad;
+} RtVertex;
+
+typedef struct RtMaterial { /* 80 B: raytracer.comp:54-82, definitions.hpp:45-73 */
+    float albedo[4];
+    float subsurface[4];
+    float specular_tint[4];
+    float emission_color[4];
+    float roughness;
+    float metallic;
+    float ior;
+    float trs_weight;
+} RtMaterial;
+
+typedef struct RtLight {    /* 48 B: raytracer.comp:47-52, definitions.hpp:76-81 */
+    float   pos_angle_aux[4];
+    float   color_str[4];
+    int32_t type;
+    float   accumulated_str;
+    int32_t _pad[2];
+} RtLight;
+
+typedef struct RtMeshInfo { /* 12 B: raytracer.comp:98-102, definitions.hpp:83-87 */
+    uint32_t index_start;
+    uint32_t index_end;
+    int32_t  material;
+} RtMeshInfo;
+
+/* Camera uniform block, std140, 336 B (raytracer.comp:27-35; host main.cpp:141-150).
+ * Matrices are column-major.  The kernels read viewInv, position and tanHalfFOV only. */
+typedef struct RtCamera {
+    float view[16];
+    float viewInv[16];
+    float proj[16];
+    float projInv[16];
+    float viewproj[16];
+    float position[3];
+    float tanHalfFOV;
+} RtCamera;
+
+/* Push-constant block, 44 B (raytracer.comp:127-137; host main.cpp:158-169).  The host
+ * struct's 1-byte bool is widened to the 32-bit bool the shader actually reads. */
+typedef struct RtPushConstants {
+    float    time;
+    uint32_t frameCount;
+    int32_t  total_lights;
+    float    lights_strength_sum;
+    float    world_up[3];
+    uint32_t reset_frame_accumulation;
+    int32_t  total_spheres;
+    int32_t  total_triangles;
+    int32_t  total_meshes;
+} RtPushConstants;
+
+/* Nearest-hit search strategy.  Both give the reference's result (lowest t; exact-t ties
+ * resolved as the flat loops of raytracer.comp:469-508 / 408-464 resolve them). */
+enum { RT_ACCEL_FLAT = 0,   /* the reference's three flat loops, every ray x every primitive */
+       RT_ACCEL_BVH  = 1 }; /* binary BVH over all primitives, same winner                    */
+
+/* Per-frame parameters that the reference hard-codes in the shader
+ * (rays_per_pixel = 5, max_bounces = 20: raytracer.comp:117-118) plus the row-strip
+ * partition used to split one frame over several GPUs.  rt_default_params() fills the
+ * reference's values. */
+typedef struct RtParams {
+    int32_t spp;          /* rays_per_pixel                                                   */
+    int32_t max_bounces;  /* path loop runs bounce = 0..max_bounces inclusive                 */
+    int32_t accel;        /* RT_ACCEL_*                                                        */
+    int32_t strip_rows;   /* height of one row strip; <= 0: this context renders every row    */
+    int32_t strip_count;  /* number of contexts sharing the frame (>= 1)                       */
+    int32_t strip_index;  /* this context renders rows y with (y/strip_rows)%strip_count==idx  */
+    uint32_t flags;       /* RT_FLAG_*                                                         */
+} RtParams;
+
+enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id per pixel       */
+       RT_FLAG_PATH_HASH   = 2u,   /* record a hash of every nearest-hit id along the paths    */
+       RT_FLAG_COUNT_RAYS  = 4u,   /* count nearest-hit searches (1 ray = 1 hit_scene call)    */
+       RT_FLAG_TRAVERSAL_STATS = 8u /* count BVH nodes visited / primitives tested             */ };
+
+typedef struct RtStats {
+    uint64_t rays;          /* nearest-hit searches in the last frame (needs COUNT_RAYS)       */
+    uint64_t nodes_visited; /* BVH nodes whose children were box-tested (needs TRAVERSAL_STATS)*/
+    uint64_t prims_tested;  /* primitive intersection tests (needs TRAVERSAL_STATS)            */
+    float    kernel_ms;     /* HIP-event time of the last frame's render kernel                */
+    int32_t  bvh_nodes;     /* nodes in the device BVH                                         */
+    int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */
+    int32_t  total_prims;   /* spheres + triangles + mesh triangles                            */
+} RtStats;
+
+typedef struct RtContext RtContext;
+
+/* ------------------------------------------------------------------ device path */
+
+/* Replaces device/queue selection + compute pipeline creation
+ * (main.cpp:799-946 pickPhysicalDevice/createLogicalDevice, 1127-1186 createComputePipeline).
+ * Fails with RT_ERR_HIP when no gfx950 device / HIP runtime is usable. */
+int rt_create(int device_ordinal, RtContext** out_ctx);
+
+/* Replaces cleanup() of the scene/accumulation/output buffers (main.cpp:311-382). */
+int rt_destroy(RtContext* ctx);
+
+/* Replaces createShaderStorageBuffers / createSSBOVector (main.cpp:1555-1593): the seven
+ * scene vectors in binding order 1..7 (raytracer.comp:145-171).  Host arrays stay owned
+ * by the caller and are copied; counts may be 0 with a non-null pointer (the reference
+ * keeps one placeholder element per vector, scene.cpp:26-32).  Builds the device-side
+ * SoA triangle arrays and the BVH. */
+int rt_upload_scene(RtContext* ctx,
+                    const RtSphere* spheres, int32_t n_spheres,
+                    const RtMaterial* materials, int32_t n_materials,
+                    const RtLight* lights, int32_t n_lights,
+                    const RtTriangle* triangles, int32_t n_triangles,
+                    const RtVertex* vertices, int32_t n_vertices,
+                    const uint32_t* indices, int32_t n_indices,
+                    const RtMeshInfo* meshes, int32_t n_meshes);
+
+/* Replaces createImageBuffer + createFrameAccumulationBuffers and their re-creation on
+ * resize (main.cpp:1501-1552, 1596-1606, 1396-1420): allocates ZEROED accumulation
+ * (float4 per pixel), sample-count (int32 per pixel) and BGRA8 output buffers. */
+int rt_resize(RtContext* ctx, int32_t width, int32_t height);
+
+/* Same role as rt_resize but the caller provides (and keeps owning) the device memory,
+ * e.g. torch tensors that a collective library reads directly.  Nothing is zeroed. */
+int rt_bind_framebuffer(RtContext* ctx, int32_t width, int32_t height,
+                        void* d_accum_float4, void* d_counts_int32, void* d_bgra8);
+
+/* One reference frame: updateUniformBuffer + push constants + vkCmdDispatch
+ * (main.cpp:1466-1497, 1424-1438, 1234-1241) = one execution of raytracer.comp::main per
+ * pixel (raytracer.comp:956-996), including reset_frame_accumulation and the accumulate /
+ * BGRA8 store.  Asynchronous on the context's stream. params == NULL: reference defaults. */
+int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pc,
+                    const RtParams* params);
+
+/* Recompute the BGRA8 image from the accumulation buffers (raytracer.comp:992-995) after
+ * they were combined across GPUs. */
+int rt_resolve(RtContext* ctx);
+
+/* Replaces the output-image copy (main.cpp:1275 vkCmdCopyImage): w*h*4 bytes, B,G,R,A. */
+int rt_read_output_bgra8(RtContext* ctx, void* dst);
+/* Read back accumulated_colors (w*h float4) and sample_counts (w*h int32); either may be NULL. */
+int rt_read_accum(RtContext* ctx, float* accum_float4, int32_t* counts);
+/* Debug outputs with no counterpart in the reference (its Hit struct has no id field):
+ * primitive id of sample 0's primary hit (-1 = miss; spheres [0,S), triangles [S,S+T),
+ * mesh triangles S+T+index/3) and the per-pixel path hash.  Either may be NULL. */
+int rt_read_debug(RtContext* ctx, int32_t* primary_ids, uint32_t* path_hash);
+
+int rt_get_stats(RtContext* ctx, RtStats* out);
+/* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
+int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);
+/* The context's hipStream_t. */
+void* rt_get_stream(RtContext* ctx);
+/* Replaces vkWaitForFences / vkQueueWaitIdle (main.cpp:1310-1312). */
+int rt_sync(RtContext* ctx);
+
+const char* rt_last_error(RtContext* ctx); /* ctx may be NULL: error of the last failed rt_create */
+void rt_default_params(RtParams* out);     /* spp 5, max_bounces 20, BVH, all rows, no flags     */
+int  rt_abi_version(void);
+
+/* ------------------------------------------------------------------ host scene surface
+ * C access to the C++ Scene builder that mirrors src/scene.hpp:8-37 / src/scene.cpp. */
+typedef struct RtScene RtScene;
+
+enum { RT_SCENE_EMPTY = 0,
+       RT_SCENE_CORNELL_STAR = 1,   /* Scene::createCornellBox verbatim (scene.cpp:350-695)    */
+       RT_SCENE_PRESET1 = 2,        /* Scene::createPreset1 (scene.cpp:37-348)                  */
+       RT_SCENE_CORNELL_TEAPOT = 3, /* Cornell box with teapot.glb in place of star.glb         */
+       RT_SCENE_TEAPOT_GRID = 4 };  /* 13x13 teapots baked into one mesh (~1.07 M triangles)    */
+
+int rt_scene_create(int preset, const char* assets_dir, RtScene** out);
+int rt_scene_destroy(RtScene* s);
+/* Builder calls, same meaning as Scene::addMaterial/addSphere/addTriangle/addQuad/addLight/
+ * addModel (scene.cpp:716-846).  rt_scene_add_material returns the material index (>= 0). */
+int rt_scene_add_material(RtScene* s, const RtMaterial* m);
+int rt_scene_add_sphere(RtScene* s, const float pos[3], float r, int32_t mat);
+int rt_scene_add_triangle(RtScene* s, const float v0[3], const float v1[3], const float v2[3], int32_t mat);
+int rt_scene_add_quad(RtScene* s, const float v0[3], const float v1[3], const float v2[3], const float v3[3], int32_t mat);
+int rt_scene_add_light(RtScene* s, const float pos_angle_aux[4], const float color_str[4], int32_t type);
+int rt_scene_add_model(RtScene* s, const char* file_name, const float pos[3],
+                       float pitch, float yaw, float roll, float scale, int32_t material);
+
+typedef struct RtSceneView {  /* borrowed pointers into the RtScene, valid until it changes */
+    const RtSphere* spheres;     int32_t n_spheres;    /* vector sizes (>= 1: placeholder rule) */
+    const RtMaterial* materials; int32_t n_materials;
+    const RtLight* lights;       int32_t n_lights;
+    const RtTriangle* triangles; int32_t n_triangles;
+    const RtVertex* vertices;    int32_t n_vertices;
+    const uint32_t* indices;     int32_t n_indices;
+    const RtMeshInfo* meshes;    int32_t n_meshes;
+    int32_t total_spheres, total_triangles, total_meshes, total_lights; /* scene.hpp:18-21 */
+    float   lights_strength_sum;                                          /* scene.hpp:17    */
+} RtSceneView;
+int rt_scene_view(const RtScene* s, RtSceneView* out);
+/* rt_upload_scene with the scene's vectors and total_* counts. */
+int rt_upload_scene_from(RtContext* ctx, const RtScene* s);
+
+/* Camera block as updateUniformBuffer fills it (main.cpp:1466-1497) from a pose. */
+int rt_camera_look(RtCamera* out, const float pos[3], const float front[3], const float up[3],
+                   float fov_degrees, int32_t width, int32_t height);
+/* The reference's initial pose after its first updateCamera(): position (2.75,2.75,-6),
+ * front +z, up +y, fov 50 (main.cpp:75-86, 554-565). */
+int rt_camera_default(RtCamera* out, int32_t width, int32_t height);
+/* Push constants as updatePushConstantsPre fills them (main.cpp:1424-1438). */
+int rt_push_constants(RtPushConstants* out, const RtScene* s, float time, uint32_t frame_count,
+                      int reset_accumulation);
+
+/* Host BVH statistics for a scene (no GPU needed): node count, depth, SAH cost. */
+int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

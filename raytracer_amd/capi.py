@@ -1,0 +1,170 @@
+"""ctypes view of the C ABI declared in include/rt_abi.h.
+
+This module only loads ``lib/libraytracer_amd.so`` and mirrors its structs and
+prototypes; it contains no rendering logic and no fallback: if the shared library is
+missing, loading raises.  The library is built by ``raytracer_amd/csrc/Makefile``
+(see ``__graft_entry__.build``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libraytracer_amd.so")
+REPO_ROOT = os.path.dirname(_HERE)
+ASSETS_DIR = os.path.join(REPO_ROOT, "assets") + os.sep
+
+RT_OK = 0
+RT_ERR_INVALID_ARGUMENT = -1
+RT_ERR_HIP = -2
+RT_ERR_NO_SCENE = -3
+RT_ERR_NO_FRAMEBUFFER = -4
+RT_ERR_UNSUPPORTED = -5
+RT_ERR_IO = -6
+RT_ERR_TOO_LARGE = -7
+
+RT_ACCEL_FLAT = 0
+RT_ACCEL_BVH = 1
+
+RT_FLAG_PRIMARY_IDS = 1
+RT_FLAG_PATH_HASH = 2
+RT_FLAG_COUNT_RAYS = 4
+RT_FLAG_TRAVERSAL_STATS = 8
+
+RT_SCENE_EMPTY = 0
+RT_SCENE_CORNELL_STAR = 1
+RT_SCENE_PRESET1 = 2
+RT_SCENE_CORNELL_TEAPOT = 3
+RT_SCENE_TEAPOT_GRID = 4
+
+RT_LIGHT_AMBIENT, RT_LIGHT_SPHERE, RT_LIGHT_POINT, RT_LIGHT_DIRECTIONAL = 0, 1, 2, 3
+RT_LIGHT_CONE, RT_LIGHT_AREA, RT_LIGHT_TRIANGLE = 4, 5, 6
+
+
+class RtSphere(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("r", C.c_float), ("mat", C.c_int32), ("_pad", C.c_int32 * 3)]
+
+
+class RtTriangle(C.Structure):
+    _fields_ = [("v0", C.c_float * 3), ("_p0", C.c_float), ("v1", C.c_float * 3), ("_p1", C.c_float),
+                ("v2", C.c_float * 3), ("_p2", C.c_float), ("normal", C.c_float * 3), ("mat", C.c_int32)]
+
+
+class RtVertex(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("_pad", C.c_float)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 4), ("subsurface", C.c_float * 4), ("specular_tint", C.c_float * 4),
+                ("emission_color", C.c_float * 4), ("roughness", C.c_float), ("metallic", C.c_float),
+                ("ior", C.c_float), ("trs_weight", C.c_float)]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("pos_angle_aux", C.c_float * 4), ("color_str", C.c_float * 4), ("type", C.c_int32),
+                ("accumulated_str", C.c_float), ("_pad", C.c_int32 * 2)]
+
+
+class RtMeshInfo(C.Structure):
+    _fields_ = [("index_start", C.c_uint32), ("index_end", C.c_uint32), ("material", C.c_int32)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("viewInv", C.c_float * 16), ("proj", C.c_float * 16),
+                ("projInv", C.c_float * 16), ("viewproj", C.c_float * 16), ("position", C.c_float * 3),
+                ("tanHalfFOV", C.c_float)]
+
+
+class RtPushConstants(C.Structure):
+    _fields_ = [("time", C.c_float), ("frameCount", C.c_uint32), ("total_lights", C.c_int32),
+                ("lights_strength_sum", C.c_float), ("world_up", C.c_float * 3),
+                ("reset_frame_accumulation", C.c_uint32), ("total_spheres", C.c_int32),
+                ("total_triangles", C.c_int32), ("total_meshes", C.c_int32)]
+
+
+class RtParams(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("max_bounces", C.c_int32), ("accel", C.c_int32), ("strip_rows", C.c_int32),
+                ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("flags", C.c_uint32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
+                ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
+                ("total_prims", C.c_int32)]
+
+
+class RtSceneView(C.Structure):
+    _fields_ = [("spheres", C.POINTER(RtSphere)), ("n_spheres", C.c_int32),
+                ("materials", C.POINTER(RtMaterial)), ("n_materials", C.c_int32),
+                ("lights", C.POINTER(RtLight)), ("n_lights", C.c_int32),
+                ("triangles", C.POINTER(RtTriangle)), ("n_triangles", C.c_int32),
+                ("vertices", C.POINTER(RtVertex)), ("n_vertices", C.c_int32),
+                ("indices", C.POINTER(C.c_uint32)), ("n_indices", C.c_int32),
+                ("meshes", C.POINTER(RtMeshInfo)), ("n_meshes", C.c_int32),
+                ("total_spheres", C.c_int32), ("total_triangles", C.c_int32), ("total_meshes", C.c_int32),
+                ("total_lights", C.c_int32), ("lights_strength_sum", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/rt_abi.h declares
+_P = C.c_void_p
+PROTOTYPES = {
+    "rt_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "rt_destroy": (C.c_int, [_P]),
+    "rt_upload_scene": (C.c_int, [_P, C.POINTER(RtSphere), C.c_int32, C.POINTER(RtMaterial), C.c_int32,
+                                  C.POINTER(RtLight), C.c_int32, C.POINTER(RtTriangle), C.c_int32,
+                                  C.POINTER(RtVertex), C.c_int32, C.POINTER(C.c_uint32), C.c_int32,
+                                  C.POINTER(RtMeshInfo), C.c_int32]),
+    "rt_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "rt_bind_framebuffer": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rt_render_frame": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams)]),
+    "rt_resolve": (C.c_int, [_P]),
+    "rt_read_output_bgra8": (C.c_int, [_P, _P]),
+    "rt_read_accum": (C.c_int, [_P, _P, _P]),
+    "rt_read_debug": (C.c_int, [_P, _P, _P]),
+    "rt_get_stats": (C.c_int, [_P, C.POINTER(RtStats)]),
+    "rt_get_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "rt_get_stream": (_P, [_P]),
+    "rt_sync": (C.c_int, [_P]),
+    "rt_last_error": (C.c_char_p, [_P]),
+    "rt_default_params": (None, [C.POINTER(RtParams)]),
+    "rt_abi_version": (C.c_int, []),
+    "rt_scene_create": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(_P)]),
+    "rt_scene_destroy": (C.c_int, [_P]),
+    "rt_scene_add_material": (C.c_int, [_P, C.POINTER(RtMaterial)]),
+    "rt_scene_add_sphere": (C.c_int, [_P, C.POINTER(C.c_float), C.c_float, C.c_int32]),
+    "rt_scene_add_triangle": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
+    "rt_scene_add_quad": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.c_int32]),
+    "rt_scene_add_light": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
+    "rt_scene_add_model": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int32]),
+    "rt_scene_view": (C.c_int, [_P, C.POINTER(RtSceneView)]),
+    "rt_upload_scene_from": (C.c_int, [_P, _P]),
+    "rt_camera_look": (C.c_int, [C.POINTER(RtCamera), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_int32]),
+    "rt_camera_default": (C.c_int, [C.POINTER(RtCamera), C.c_int32, C.c_int32]),
+    "rt_push_constants": (C.c_int, [C.POINTER(RtPushConstants), _P, C.c_float, C.c_uint32, C.c_int]),
+    "rt_scene_bvh_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libraytracer_amd.so (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

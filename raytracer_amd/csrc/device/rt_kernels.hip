@@ -1,0 +1,508 @@
+// rt_kernels.hip — the path-tracing kernel for gfx950 (MI355X).
+//
+// One launch = one execution of shaders/raytracer.comp::main for every pixel this context
+// owns (raytracer.comp:956-996).  The per-pixel program of the shader is restructured as
+// a per-lane state machine so that the only expensive operation, the nearest-hit search
+// (hit_scene, raytracer.comp:469-508), is executed at ONE program point by all 64 lanes
+// of a wave together — whatever sample, bounce or purpose (path vertex or light
+// visibility) each lane is at.  Lanes whose pixel is finished pull the next pixel from a
+// wave-local reserve refilled by one atomic per 64 pixels (ballot + popcount ranking), so
+// terminated paths do not leave lanes idle.  Each pixel is still computed by exactly one
+// lane, sequentially, with its own RNG state: results do not depend on scheduling.
+#include "rt_kernels.h"
+#include "rt_shade.h"
+
+namespace rtd {
+
+namespace {
+
+RT_DEV bool surrounds(float x) { return 0.005f < x && kInf > x; }  // Interval(0.005, PINF), raytracer.comp:310-312
+
+// One primitive against one ray; keeps the winner under the reference's tie rules
+// (lower t; equal t: lower prio).  Triangle: raytracer.comp:366-406 / 412-449 with the two
+// edges precomputed; sphere: raytracer.comp:334-361.
+RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
+                             int& best_idx) {
+    const float4 A = recs[3 * idx + 0];
+    const float4 B = recs[3 * idx + 1];
+    const float4 C = recs[3 * idx + 2];
+    const int prio = __float_as_int(B.w);
+    float t;
+    if (__float_as_int(C.w) < 0) {  // sphere: A.xyz centre, B.x radius
+        V3 oc = v3(A.x, A.y, A.z) - ro;
+        float a = dot(rd, rd);
+        float h = dot(rd, oc);
+        float c = dot(oc, oc) - B.x * B.x;
+        float disc = h * h - a * c;
+        if (disc < 0.0f) return;
+        float srtd = g_sqrt(disc);
+        t = (h - srtd) / a;
+        if (!surrounds(t)) {
+            t = (h + srtd) / a;
+            if (!surrounds(t)) return;
+        }
+    } else {  // triangle: A.xyz = v0, B.xyz = v1 - v0, C.xyz = v2 - v0
+        V3 e1 = v3(B.x, B.y, B.z);
+        V3 e2 = v3(C.x, C.y, C.z);
+        V3 h = cross(rd, e2);
+        float a = dot(e1, h);
+        if (g_abs(a) < 1e-6f) return;
+        float f = 1.0f / a;
+        V3 s = ro - v3(A.x, A.y, A.z);
+        float u = f * dot(s, h);
+        if (u < 0.0f || u > 1.0f) return;
+        V3 q = cross(s, e1);
+        float v = f * dot(rd, q);
+        if (v < 0.0f || u + v > 1.0f) return;
+        t = f * dot(e2, q);
+        if (!surrounds(t)) return;
+    }
+    if (t < best_t || (t == best_t && prio < best_prio)) {
+        best_t = t;
+        best_prio = prio;
+        best_idx = idx;
+    }
+}
+
+// The reference's search: every primitive, in the order of its three loops.
+RT_DEV void trace_flat(const DeviceScene& sc, V3 ro, V3 rd, float& best_t, int& best_idx) {
+    int best_prio = 0x7fffffff;
+    for (int i = 0; i < sc.n_prims; ++i) intersect_record(sc.prims_flat, i, ro, rd, best_t, best_prio, best_idx);
+}
+
+// Stack entries: >= 0 internal node index; < 0 a leaf: bit 31 | (count-1) << 28 | first record.
+RT_DEV int encode_child(int child, int count) { return count > 0 ? (int)(0x80000000u | ((uint32_t)(count - 1) << 28) | (uint32_t)child) : child; }
+
+// Binary BVH, both child boxes in the parent, per-lane stack in LDS (column `tid` of a
+// [depth][block] array: lane-private, bank = tid mod 32 at every depth, so no conflicts).
+template <bool STATS>
+RT_DEV void trace_bvh(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, float& best_t, int& best_idx,
+                      uint32_t& n_nodes, uint32_t& n_tests) {
+    int best_prio = 0x7fffffff;
+    // Slab arithmetic runs on a direction with no zero component; the boxes are padded on
+    // the host by far more than the half-ulp origin perturbation the fused form implies.
+    float dx = (g_abs(rd.x) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.x) : rd.x;
+    float dy = (g_abs(rd.y) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.y) : rd.y;
+    float dz = (g_abs(rd.z) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.z) : rd.z;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float ox = -(ro.x * ix), oy = -(ro.y * iy), oz = -(ro.z * iz);
+    const float4* __restrict__ nodes = sc.nodes;
+
+    int sp = 0;
+    int cur = 0;  // node 0 is always internal
+    for (;;) {
+        if (cur >= 0) {
+            const float4 q0 = nodes[4 * cur + 0];
+            const float4 q1 = nodes[4 * cur + 1];
+            const float4 q2 = nodes[4 * cur + 2];
+            const float4 q3 = nodes[4 * cur + 3];
+            if (STATS) n_nodes++;
+            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+            float a0 = __builtin_fmaf(q0.x, ix, ox), b0 = __builtin_fmaf(q0.w, ix, ox);
+            float a1 = __builtin_fmaf(q0.y, iy, oy), b1 = __builtin_fmaf(q1.x, iy, oy);
+            float a2 = __builtin_fmaf(q0.z, iz, oz), b2 = __builtin_fmaf(q1.y, iz, oz);
+            float tmin0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), 0.0f));
+            float tmax0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), best_t));
+            float c0 = __builtin_fmaf(q1.z, ix, ox), d0 = __builtin_fmaf(q2.y, ix, ox);
+            float c1 = __builtin_fmaf(q1.w, iy, oy), d1 = __builtin_fmaf(q2.z, iy, oy);
+            float c2 = __builtin_fmaf(q2.x, iz, oz), d2 = __builtin_fmaf(q2.w, iz, oz);
+            float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
+            float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), best_t));
+            const bool hit0 = tmin0 <= tmax0 * 1.0000005f;
+            const bool hit1 = tmin1 <= tmax1 * 1.0000005f;
+            int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
+            int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
+            if (hit0 && hit1) {
+                if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
+                stack[sp * kBlock] = (uint32_t)r1;
+                sp++;
+                cur = r0;
+            } else if (hit0) {
+                cur = r0;
+            } else if (hit1) {
+                cur = r1;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                cur = (int)stack[sp * kBlock];
+            }
+        } else {
+            const int first = cur & 0x0fffffff;
+            const int count = ((cur >> 28) & 7) + 1;
+            for (int k = 0; k < count; ++k) intersect_record(sc.prims_bvh, first + k, ro, rd, best_t, best_prio, best_idx);
+            if (STATS) n_tests += (uint32_t)count;
+            if (sp == 0) break;
+            sp--;
+            cur = (int)stack[sp * kBlock];
+        }
+    }
+}
+
+// Hit record of the winning primitive (raytracer.comp:354-358, 398-403, 454-461).
+RT_DEV void make_hit(const DeviceScene& sc, const float4* __restrict__ recs, int idx, float t, V3 ro, V3 rd, Hit& h,
+                     int& prim_id) {
+    const float4 A = recs[3 * idx + 0];
+    const float4 B = recs[3 * idx + 1];
+    const float4 C = recs[3 * idx + 2];
+    prim_id = __float_as_int(A.w);
+    const int matbits = __float_as_int(C.w);
+    h.t = t;
+    h.p = ro + t * rd;
+    V3 outward;
+    if (matbits < 0) {
+        h.mat = matbits & 0x7fffffff;
+        outward = (h.p - v3(A.x, A.y, A.z)) / B.x;
+    } else {
+        h.mat = matbits;
+        if (prim_id < sc.n_spheres + sc.n_triangles) {
+            const float4 n = sc.triangles[4 * (prim_id - sc.n_spheres) + 3];  // stored Triangle.normal
+            outward = v3(n.x, n.y, n.z);
+        } else {
+            outward = normalize(cross(v3(B.x, B.y, B.z), v3(C.x, C.y, C.z)));
+        }
+    }
+    h.front_face = dot(rd, outward) < 0.0f;  // set_face_normal, raytracer.comp:322-329
+    h.normal = h.front_face ? outward : -outward;
+}
+
+RT_DEV uint32_t pack_unorm8(float x) {
+    float c = g_clamp(x, 0.0f, 1.0f);  // NaN -> 0
+    return (uint32_t)__builtin_rintf(c * 255.0f);
+}
+
+// raytracer.comp:984-995: accumulate one frame's colour, write acc/count as B,G,R,A bytes
+RT_DEV uint32_t resolve_pixel(float4 a, int c) {
+    float d = (float)((c > 1) ? c : 1);
+    return pack_unorm8(a.z / d) | (pack_unorm8(a.y / d) << 8) | (pack_unorm8(a.x / d) << 16) | (pack_unorm8(a.w / d) << 24);
+}
+
+enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2 };
+
+template <int ACCEL, bool STATS>
+__global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, const FrameArgs fa) {
+    __shared__ uint32_t s_stack[(ACCEL == 1) ? (kStackDepth * kBlock) : 1];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const float4* __restrict__ recs = (ACCEL == 1) ? sc.prims_bvh : sc.prims_flat;
+
+    // ---- per-lane path state
+    int state = ST_IDLE;
+    uint32_t seed = 0;
+    int px = 0, py = 0, sample = 0, bounce = 0;
+    V3 ro = v3(0.0f), rd = v3(0.0f, 0.0f, 1.0f);  // path ray
+    V3 qo = ro, qd = rd;                            // ray handed to the nearest-hit search
+    V3 att = v3(1.0f), col = v3(0.0f), pix = v3(0.0f);
+    uint32_t phash = 0;
+    // saved across a light-visibility search
+    Hit sh;
+    sh.p = v3(0.0f); sh.normal = v3(0.0f); sh.mat = 0; sh.t = 0.0f; sh.front_face = false;
+    V3 s_L = v3(0.0f);
+    float s_d = 0.0f;
+    int s_light = 0;
+    // counters
+    uint32_t n_rays = 0, n_nodes = 0, n_tests = 0;
+    // wave-uniform pixel reserve
+    uint32_t res_next = 0, res_left = 0;
+    bool exhausted = false;
+
+    const float aspect = (float)fa.width / (float)fa.height;  // raytracer.comp:187
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill idle lanes
+        const unsigned long long idle = __ballot(state == ST_IDLE);
+        if (idle != 0ull) {
+            if (res_left == 0u && !exhausted) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&fa.counters[0], 64u);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= fa.total_slots) {
+                    exhausted = true;
+                } else {
+                    res_next = b;
+                    res_left = fa.total_slots - b;
+                    if (res_left > 64u) res_left = 64u;
+                }
+            }
+            if (res_left != 0u) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (state == ST_IDLE && rank < res_left) {
+                    const uint32_t slot = res_next + rank;
+                    const uint32_t tile = slot >> 6, in = slot & 63u;
+                    const int x = (int)(tile % (uint32_t)fa.tiles_x) * 8 + (int)(in & 7u);
+                    const int r = (int)(tile / (uint32_t)fa.tiles_x) * 8 + (int)(in >> 3);
+                    if (x < fa.width && r < fa.owned_rows) {
+                        int y = r;
+                        if (fa.strip_rows > 0)
+                            y = ((r / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (r % fa.strip_rows);
+                        px = x;
+                        py = y;
+                        // raytracer.comp:959-961
+                        seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
+                        pix = v3(0.0f);
+                        sample = 0;
+                        phash = 0;
+                        state = -1;  // start a sample below
+                    }
+                }
+                uint32_t want = (uint32_t)__popcll(idle);
+                uint32_t granted = want < res_left ? want : res_left;
+                res_next += granted;
+                res_left -= granted;
+            }
+        }
+
+        // ------------------------------------------------------------------ begin a sample: get_ray, raytracer.comp:933-952
+        if (state == -1) {
+            float sx = rng_random(seed) - 0.5f;
+            float sy = rng_random(seed) - 0.5f;
+            float fx = (float)px + sx;
+            float fy = (float)py + sy;
+            float ndcX = 2.0f * fx / (float)fa.width - 1.0f;
+            float ndcY = 1.0f - 2.0f * fy / (float)fa.height;
+            V3 dc = normalize(v3(ndcX * aspect * fa.tan_half_fov, ndcY * fa.tan_half_fov, -1.0f));
+            const float* m = fa.view_inv;
+            V3 dw = v3(m[0] * dc.x + m[4] * dc.y + m[8] * dc.z + m[12] * 0.0f,
+                       m[1] * dc.x + m[5] * dc.y + m[9] * dc.z + m[13] * 0.0f,
+                       m[2] * dc.x + m[6] * dc.y + m[10] * dc.z + m[14] * 0.0f);
+            rd = normalize(dw);
+            ro = v3(fa.cam_pos[0], fa.cam_pos[1], fa.cam_pos[2]);
+            qo = ro;
+            qd = rd;
+            att = v3(1.0f);
+            col = v3(0.0f);
+            bounce = 0;
+            state = ST_TRACE_PATH;
+        }
+
+        if (__ballot(state != ST_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ nearest-hit search (all busy lanes together)
+        float hit_t = kInf;
+        int hit_idx = -1;
+        if (state != ST_IDLE) {
+            n_rays++;
+            if (ACCEL == 1) {
+                trace_bvh<STATS>(sc, qo, qd, &s_stack[tid], hit_t, hit_idx, n_nodes, n_tests);
+            } else {
+                trace_flat(sc, qo, qd, hit_t, hit_idx);
+                if (STATS) n_tests += (uint32_t)sc.n_prims;
+            }
+        }
+
+        // ------------------------------------------------------------------ continuation
+        bool need_shade = false, have_direct = false, end_sample = false;
+        Hit h = sh;
+        const bool is_primary = (state == ST_TRACE_PATH && sample == 0 && bounce == 0);
+        V3 Le = v3(0.0f), Ldir = v3(0.0f);
+        float light_pdf = 0.0f;
+        int prim_id = -1;
+
+        if (state == ST_TRACE_LIGHT) {
+            // second half of sample_light (raytracer.comp:617-626, 636-644, 662-671)
+            if (hit_idx >= 0) prim_id = __float_as_int(recs[3 * hit_idx].w);
+            const float4 lc = sc.lights[3 * s_light + 1];
+            const int ltype = __float_as_int(sc.lights[3 * s_light + 2].x);
+            Ldir = sh.normal;
+            light_pdf = 0.00001f;
+            if (ltype == 3 /* DIRECTIONAL */) {
+                if (hit_idx < 0) {
+                    Ldir = s_L;
+                    light_pdf = 1.0f;
+                    Le = v3(lc.x, lc.y, lc.z);
+                }
+            } else if (hit_idx >= 0 && g_abs(s_d - hit_t) < 0.1f) {
+                float d2 = s_d * s_d;
+                Ldir = s_L;
+                light_pdf = (ltype == 1 /* SPHERE */) ? (1.0f / 2.0f / kPi) : 1.0f;
+                Le = g_clamp(v3(lc.x, lc.y, lc.z) * lc.w / d2, 0.0f, 1.0f);
+            }
+            have_direct = true;
+            need_shade = true;
+        } else if (state == ST_TRACE_PATH) {
+            if (hit_idx < 0) {
+                col = col + att * v3(0.3f);  // skybox_color_grey, raytracer.comp:570-577, 924
+                end_sample = true;
+            } else {
+                make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);
+                const Material mat = load_material(sc.materials, h.mat);
+                if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
+                    ro = h.p;
+                    qo = ro;
+                    bounce++;
+                    if (bounce > fa.max_bounces) end_sample = true;
+                } else if (mat.emission_a > 0.0f) {  // raytracer.comp:901-904
+                    col = col + att * mat.emission;
+                    end_sample = true;
+                } else if (bounce == 0) {
+                    // first half of sample_light (raytracer.comp:582-616, 633-635, 653-661)
+                    need_shade = true;
+                    have_direct = true;
+                    if (!(fa.total_lights == 0 || fa.lights_strength_sum <= 0.0f)) {
+                        float rand_strength = rng_random(seed) * fa.lights_strength_sum;
+                        int low = 0, high = fa.total_lights - 1;
+                        while (low < high) {
+                            int mid = (low + high) / 2;
+                            if (rand_strength <= sc.lights[3 * mid + 2].y) high = mid; else low = mid + 1;
+                        }
+                        const float4 lp = sc.lights[3 * low + 0];
+                        const float4 lc = sc.lights[3 * low + 1];
+                        const int ltype = __float_as_int(sc.lights[3 * low + 2].x);
+                        bool search = false;
+                        if (ltype == 0 /* AMBIENT */) {
+                            Ldir = random_vec_on_hemisphere(h.normal, seed);
+                            light_pdf = 1.0f / 2.0f / kPi;
+                            Le = v3(lc.x, lc.y, lc.z);
+                        } else if (ltype == 1 /* SPHERE */) {
+                            V3 center = v3(lp.x, lp.y, lp.z);
+                            V3 center_to_point = h.p - center;
+                            V3 sphere_point = random_vec_on_hemisphere(normalize(center_to_point), seed) * lp.w + center;
+                            V3 pts = sphere_point - h.p;
+                            s_d = length(pts);
+                            s_L = normalize(pts);
+                            search = true;
+                        } else if (ltype == 3 /* DIRECTIONAL */) {
+                            V3 light_dir = -v3(lp.x, lp.y, lp.z);
+                            if (dot(h.normal, light_dir) > 0.0f) {
+                                s_L = light_dir;
+                                s_d = 0.0f;
+                                search = true;
+                            } else {
+                                Ldir = h.normal;
+                                light_pdf = 0.00001f;
+                            }
+                        } else if (ltype == 6 /* TRIANGLE */) {
+                            const int ti = (int)lp.x;
+                            const float4 t0 = sc.triangles[4 * ti + 0];
+                            const float4 t1 = sc.triangles[4 * ti + 1];
+                            const float4 t2 = sc.triangles[4 * ti + 2];
+                            float e1 = g_sqrt(rng_random(seed));
+                            float e2 = rng_random(seed);
+                            V3 tri_point = (1.0f - e1) * v3(t0.x, t0.y, t0.z) + e1 * (1.0f - e2) * v3(t1.x, t1.y, t1.z) +
+                                           e1 * e2 * v3(t2.x, t2.y, t2.z);
+                            V3 pts = tri_point - h.p;
+                            s_d = length(pts);
+                            s_L = normalize(pts);
+                            search = true;
+                        } else {
+                            // POINT / CONE / AREA fall through the shader's switch (raytracer.comp:628-651)
+                            // and return vec3(1) with L and pdf never written; they are taken as zero.
+                            Le = v3(1.0f);
+                        }
+                        if (search) {
+                            sh = h;
+                            s_light = low;
+                            qo = h.p;
+                            qd = s_L;
+                            state = ST_TRACE_LIGHT;
+                            need_shade = false;
+                        }
+                    }
+                } else {
+                    need_shade = true;
+                }
+            }
+        }
+        if (is_primary && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[py * fa.width + px] = prim_id;
+        if (state != ST_IDLE) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
+
+        if (need_shade) {
+            const Material mat = load_material(sc.materials, h.mat);
+            const V3 V = -rd;
+            if (have_direct) {  // direct_light, raytracer.comp:870-881
+                float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
+                float mat_pdf;
+                V3 fr = eval_mat(mat, Ldir, V, h, mat_pdf);
+                float pdf = power_heuristics(light_pdf, mat_pdf);
+                col = col + g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
+            }
+            // indirect bounce, raytracer.comp:913-921
+            V3 bounce_dir = sample_mat(mat, V, h, seed);
+            float mat_pdf;
+            V3 fr = eval_mat(mat, bounce_dir, V, h, mat_pdf);
+            float cos_theta = g_abs(dot(h.normal, bounce_dir));
+            att = att * g_max(v3(0.0f), fr * cos_theta / g_max(0.00001f, mat_pdf));
+            ro = h.p;
+            rd = bounce_dir;
+            qo = ro;
+            qd = rd;
+            bounce++;
+            state = ST_TRACE_PATH;
+            if (bounce > fa.max_bounces) end_sample = true;
+        }
+
+        if (end_sample) {
+            pix = pix + g_clamp(col, 0.0f, 1.0f);  // raytracer.comp:925/929, 974
+            sample++;
+            if (sample < fa.spp) {
+                state = -1;
+            } else {
+                // raytracer.comp:978-995
+                V3 c = g_pow(pix / (float)fa.spp, 1.0f / 2.2f);
+                const int idx = py * fa.width + px;
+                float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                int n = 0;
+                if (!fa.reset) {
+                    a = fa.accum[idx];
+                    n = fa.counts[idx];
+                }
+                a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0f;
+                n += 1;
+                fa.accum[idx] = a;
+                fa.counts[idx] = n;
+                fa.bgra[idx] = resolve_pixel(a, n);
+                if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[idx] = phash;
+                state = ST_IDLE;
+            }
+        }
+    }
+
+    // ---- counters: one atomic per wave
+    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        if (STATS) {
+            nn += __shfl_down(nn, off);
+            nt += __shfl_down(nt, off);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)(fa.counters + 2), r);
+        if (STATS) {
+            atomicAdd((unsigned long long*)(fa.counters + 4), nn);
+            atomicAdd((unsigned long long*)(fa.counters + 6), nt);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) resolve_kernel(const float4* __restrict__ accum, const int32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ bgra, int n) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) bgra[i] = resolve_pixel(accum[i], counts[i]);
+}
+
+}  // namespace
+
+hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int grid_blocks,
+                         hipStream_t stream) {
+    dim3 grid((unsigned)grid_blocks), block(kBlock);
+    if (accel == 1) {
+        if (stats) hipLaunchKernelGGL((render_kernel<1, true>), grid, block, 0, stream, sc, fa);
+        else hipLaunchKernelGGL((render_kernel<1, false>), grid, block, 0, stream, sc, fa);
+    } else {
+        if (stats) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, 0, stream, sc, fa);
+        else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, sc, fa);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream) {
+    if (n_pixels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, accum, counts, bgra,
+                       n_pixels);
+    return hipGetLastError();
+}
+
+}  // namespace rtd

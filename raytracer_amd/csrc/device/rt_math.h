@@ -1,0 +1,235 @@
+// rt_math.h — device-side scalar and vector arithmetic for the path-tracing kernels.
+//
+// Arithmetic contract: every GLSL operator of shaders/raytracer.comp is ONE IEEE-754
+// binary32 operation, evaluated in source order, with no fused multiply-add (this file is
+// compiled with -ffp-contract=off) and with correctly rounded division and square root.
+// GLSL built-ins whose precision Vulkan leaves to the implementation (sin, cos, tan, acos,
+// pow/exp2/log2) are fixed here to explicit polynomial evaluations in binary32 so that a
+// host restatement using the same formulas reproduces the device bit for bit.
+//   normalize(v) = v * (1 / sqrt(dot(v,v)))      dot = (x*x' + y*y') + z*z'
+//   min/max/clamp return the non-NaN operand (as shipping GPUs' min/max instructions do)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtd {
+
+#define RT_DEV __device__ __forceinline__
+
+static constexpr float kPi = 3.14159265359f;  // raytracer.comp:4
+static constexpr float kInf = __builtin_huge_valf();
+
+RT_DEV uint32_t f2u(float x) { return __float_as_uint(x); }
+RT_DEV float u2f(uint32_t x) { return __uint_as_float(x); }
+RT_DEV bool is_nan(float x) { return x != x; }
+
+RT_DEV float g_max(float x, float y) { return is_nan(x) ? y : (is_nan(y) ? x : ((x < y) ? y : x)); }
+RT_DEV float g_min(float x, float y) { return is_nan(x) ? y : (is_nan(y) ? x : ((y < x) ? y : x)); }
+RT_DEV float g_clamp(float x, float lo, float hi) { return g_min(g_max(x, lo), hi); }
+RT_DEV float g_abs(float x) { return u2f(f2u(x) & 0x7fffffffu); }
+RT_DEV float g_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+RT_DEV float g_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+RT_DEV float g_sqrt(float x) { return __fsqrt_rn(x); }
+
+// ---- trigonometry: Cody-Waite reduction by pi/4 octants + minimax polynomials ----------
+static constexpr float kFOPI = 1.27323954473516f;
+static constexpr float kDP1 = 0.78515625f;
+static constexpr float kDP2 = 2.4187564849853515625e-4f;
+static constexpr float kDP3 = 3.77489497744594108e-8f;
+static constexpr float kTrigMax = 1.0e9f;  // beyond this the octant no longer fits an int
+
+RT_DEV float poly_sin(float x, float z) {
+    return ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+}
+RT_DEV float poly_cos(float z) {
+    return ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+}
+
+RT_DEV float g_sin(float xx) {
+    float x = g_abs(xx);
+    if (!(x <= kTrigMax)) return xx - xx;  // inf, NaN and out-of-range -> NaN
+    bool neg = xx < 0.0f;
+    int j = (int)(kFOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { neg = !neg; j -= 4; }
+    x = ((x - y * kDP1) - y * kDP2) - y * kDP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? poly_cos(z) : poly_sin(x, z);
+    return neg ? -r : r;
+}
+
+RT_DEV float g_cos(float xx) {
+    float x = g_abs(xx);
+    if (!(x <= kTrigMax)) return xx - xx;
+    bool neg = false;
+    int j = (int)(kFOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { j -= 4; neg = !neg; }
+    if (j > 1) neg = !neg;
+    x = ((x - y * kDP1) - y * kDP2) - y * kDP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? poly_sin(x, z) : poly_cos(z);
+    return neg ? -r : r;
+}
+
+RT_DEV float g_tan(float xx) {
+    float x = g_abs(xx);
+    if (!(x <= kTrigMax)) return xx - xx;
+    bool neg = xx < 0.0f;
+    int j = (int)(kFOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    float z = ((x - y * kDP1) - y * kDP2) - y * kDP3;
+    float zz = z * z;
+    float r;
+    if (x > 1.0e-4f) {
+        r = (((((9.38540185543e-3f * zz + 3.11992232697e-3f) * zz + 2.44301354525e-2f) * zz + 5.34112807005e-2f) * zz +
+              1.33387994085e-1f) * zz + 3.33331568548e-1f) * zz * z + z;
+    } else {
+        r = z;
+    }
+    if (j & 2) r = -1.0f / r;
+    return neg ? -r : r;
+}
+
+// asin on [-1,1] (outside: NaN)
+RT_DEV float g_asin(float xx) {
+    float a = g_abs(xx);
+    if (!(a <= 1.0f)) return u2f(0x7fc00000u);
+    float x, z;
+    bool flag = a > 0.5f;
+    if (flag) {
+        z = 0.5f * (1.0f - a);
+        x = g_sqrt(z);
+    } else {
+        x = a;
+        z = x * x;
+    }
+    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z +
+               1.6666752422e-1f) * z * x + x;
+    if (flag) {
+        r = r + r;
+        r = 1.5707963267948966192f - r;
+    }
+    return (xx < 0.0f) ? -r : r;
+}
+
+RT_DEV float g_acos(float x) {
+    if (!(g_abs(x) <= 1.0f)) return u2f(0x7fc00000u);
+    if (x < -0.5f) return kPi - 2.0f * g_asin(g_sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * g_asin(g_sqrt(0.5f * (1.0f - x)));
+    return 1.5707963267948966192f - g_asin(x);
+}
+
+// ---- pow(x, y) = exp2(y * log2(x)), the GLSL definition ---------------------------------
+RT_DEV float g_log2(float x) {
+    if (is_nan(x) || x < 0.0f) return u2f(0x7fc00000u);
+    if (x == 0.0f) return -kInf;
+    if (x == kInf) return kInf;
+    uint32_t ix = f2u(x);
+    int e = 0;
+    if ((ix & 0x7f800000u) == 0u) {  // subnormal: renormalise by 2^23
+        x = x * 8388608.0f;
+        ix = f2u(x);
+        e = -23;
+    }
+    e += (int)((ix >> 23) & 0xffu) - 126;
+    float m = u2f((ix & 0x007fffffu) | 0x3f000000u);  // mantissa in [0.5, 1)
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m +
+                   1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m +
+               3.3333331174e-1f) * m * z;
+    y = y - 0.5f * z;  // ln(1+m) - m
+    const float kLog2EA = 0.44269504088896340735992f;  // log2(e) - 1
+    float r = y * kLog2EA;
+    r = r + m * kLog2EA;
+    r = r + y;
+    r = r + m;
+    r = r + (float)e;
+    return r;
+}
+
+RT_DEV float g_exp2(float x) {
+    if (is_nan(x)) return x;
+    if (x >= 128.0f) return kInf;
+    if (x < -126.0f) return 0.0f;
+    float fl = __builtin_floorf(x);
+    int i0 = (int)fl;
+    float f = x - fl;
+    if (f > 0.5f) {
+        i0 += 1;
+        f = f - 1.0f;
+    }
+    float p = (((((1.535336188319500e-4f * f + 1.339887440266574e-3f) * f + 9.618437357674640e-3f) * f +
+                 5.550332471162809e-2f) * f + 2.402264791363012e-1f) * f + 6.931472028550421e-1f) * f + 1.0f;
+    // i0 in [-126, 128]: scale in two exact steps so that 2^128 is never formed
+    int h = i0 / 2;
+    float s1 = u2f((uint32_t)(h + 127) << 23);
+    float s2 = u2f((uint32_t)(i0 - h + 127) << 23);
+    return (p * s1) * s2;
+}
+
+RT_DEV float g_pow(float x, float y) { return g_exp2(y * g_log2(x)); }
+
+// ---- vec3 ------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 v3(float x, float y, float z) { return {x, y, z}; }
+RT_DEV V3 v3(float s) { return {s, s, s}; }
+RT_DEV V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+RT_DEV V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+RT_DEV V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+RT_DEV V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+RT_DEV V3 operator+(V3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+RT_DEV V3 operator-(float s, V3 a) { return {s - a.x, s - a.y, s - a.z}; }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+RT_DEV float length(V3 a) { return g_sqrt(dot(a, a)); }
+RT_DEV V3 normalize(V3 a) { return a * (1.0f / g_sqrt(dot(a, a))); }
+RT_DEV V3 g_max(V3 a, V3 b) { return {g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z)}; }
+RT_DEV V3 g_clamp(V3 a, float lo, float hi) { return {g_clamp(a.x, lo, hi), g_clamp(a.y, lo, hi), g_clamp(a.z, lo, hi)}; }
+RT_DEV V3 g_mix(V3 x, V3 y, float a) { return {g_mix(x.x, y.x, a), g_mix(x.y, y.y, a), g_mix(x.z, y.z, a)}; }
+RT_DEV V3 g_pow(V3 a, float e) { return {g_pow(a.x, e), g_pow(a.y, e), g_pow(a.z, e)}; }
+// GLSL reflect / refract
+RT_DEV V3 g_reflect(V3 I, V3 N) { return I - 2.0f * dot(N, I) * N; }
+RT_DEV V3 g_refract(V3 I, V3 N, float eta) {
+    float d = dot(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return v3(0.0f);
+    return eta * I - (eta * d + g_sqrt(k)) * N;
+}
+
+// ---- RNG (raytracer.comp:193-211) ----------------------------------------------------------
+RT_DEV uint32_t rng_hash(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+RT_DEV uint32_t rng_xorshift(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+// float(state) / 4294967295.0: the divisor literal is a binary32 constant and rounds to
+// 2^32, so the result lies in [0, 1] and CAN equal 1.0.
+RT_DEV float rng_random(uint32_t& s) { return (float)rng_xorshift(s) / 4294967296.0f; }
+
+}  // namespace rtd

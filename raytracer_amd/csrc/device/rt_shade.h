@@ -1,0 +1,200 @@
+// rt_shade.h — material evaluation / sampling and hit-record helpers of the path tracer,
+// following shaders/raytracer.comp function by function (line ranges cited per function).
+#pragma once
+#include "rt_math.h"
+
+namespace rtd {
+
+struct Material {  // raytracer.comp:54-82
+    V3 albedo;        float albedo_a;
+    V3 subsurface;    float subsurface_a;
+    V3 specular_tint; float specular_tint_a;
+    V3 emission;      float emission_a;
+    float roughness, metallic, ior, trs_weight;
+};
+
+struct Hit {  // raytracer.comp:108-114
+    V3 p;
+    V3 normal;
+    int mat;
+    float t;
+    bool front_face;
+};
+
+RT_DEV Material load_material(const float4* __restrict__ mats, int idx) {
+    const float4* m = mats + 5 * idx;
+    float4 a = m[0], s = m[1], sp = m[2], e = m[3], g = m[4];
+    Material r;
+    r.albedo = v3(a.x, a.y, a.z);         r.albedo_a = a.w;
+    r.subsurface = v3(s.x, s.y, s.z);     r.subsurface_a = s.w;
+    r.specular_tint = v3(sp.x, sp.y, sp.z); r.specular_tint_a = sp.w;
+    r.emission = v3(e.x, e.y, e.z);       r.emission_a = e.w;
+    r.roughness = g.x; r.metallic = g.y; r.ior = g.z; r.trs_weight = g.w;
+    return r;
+}
+
+// raytracer.comp:225-243
+RT_DEV V3 random_unit_vec(uint32_t& seed) {
+    float phi = (2.0f * kPi) * rng_random(seed);
+    float theta = g_acos(2.0f * rng_random(seed) - 1.0f);
+    float sin_theta = g_sin(theta);
+    return v3(sin_theta * g_cos(phi), sin_theta * g_sin(phi), g_cos(theta));
+}
+RT_DEV V3 random_vec_on_hemisphere(V3 normal, uint32_t& seed) {
+    V3 r = random_unit_vec(seed);
+    return (dot(r, normal) > 0.0f) ? r : -r;
+}
+
+// raytracer.comp:250-254
+RT_DEV float power_heuristics(float a, float b) {
+    float a2 = a * a;
+    float b2 = b * b;
+    return a2 / g_max(a2 + b2, 0.000001f);
+}
+
+// raytracer.comp:260-267
+RT_DEV V3 sphere_to_cartesian(float theta, float phi) {
+    float sin_t = g_sin(theta);
+    return v3(sin_t * g_cos(phi), sin_t * g_sin(phi), g_cos(theta));
+}
+
+// raytracer.comp:279-292
+RT_DEV V3 align_to_world(V3 X, V3 N) {
+    V3 up = (g_abs(N.z) > 0.9999999f) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 0.0f, 1.0f);
+    V3 T = normalize(cross(up, N));
+    V3 B = cross(N, T);
+    return T * X.x + B * X.y + N * X.z;
+}
+
+// raytracer.comp:683-695
+RT_DEV V3 reflectance_v(float cos_theta, V3 F0) {
+    float p = g_pow(1.0f - cos_theta, 5.0f);
+    return g_clamp(F0 + (1.0f - F0) * p, 0.0f, 1.0f);
+}
+RT_DEV float fresnel_dielectric(float cos_theta_i, float eta) {
+    float r0 = (1.0f - eta) / (1.0f + eta);
+    float F0 = r0 * r0;
+    return F0 + (1.0f - F0) * g_pow(1.0f - cos_theta_i, 5.0f);
+}
+
+// raytracer.comp:699-705
+RT_DEV float ggx_distribution(float alpha, V3 N, V3 H) {
+    float alpha_squared = alpha * alpha;
+    float d = dot(N, H);
+    if (d == 0.0f) d = 0.000001f;
+    float x = d * d * (alpha_squared - 1.0f) + 1.0f;
+    return alpha_squared / (kPi * x * x);
+}
+
+// raytracer.comp:716-727 (H is unused by the reference too)
+RT_DEV float G1_GGX(V3 v, V3 N, float alpha) {
+    float voN = dot(v, N);
+    if (voN == 0.0f) voN = 0.0000001f;
+    float tan_theta_x = g_tan(g_acos(voN));
+    float alpha_tan = alpha * tan_theta_x;
+    return 2.0f / (1.0f + g_sqrt(1.0f + alpha_tan * alpha_tan));
+}
+
+// raytracer.comp:736-748
+RT_DEV V3 sample_ggx(float roughness, V3 V, V3 N, uint32_t& seed) {
+    float e1 = rng_random(seed);
+    float e2 = rng_random(seed);
+    float alpha = roughness * roughness;
+    float theta = g_acos(g_sqrt((1.0f - e1) / (1.0f + (alpha - 1.0f) * e1)));
+    float phi = (2.0f * kPi) * e2;
+    V3 H_tan = sphere_to_cartesian(theta, phi);
+    V3 H = align_to_world(H_tan, N);
+    if (dot(V, H) < 0.0f) H = -H;
+    return normalize(H);
+}
+
+// raytracer.comp:751-785
+RT_DEV V3 sample_mat(const Material& mat, V3 V, const Hit& rec, uint32_t& seed) {
+    if (mat.trs_weight < rng_random(seed)) {
+        V3 H = sample_ggx(mat.roughness, V, rec.normal, seed);
+        return normalize(g_reflect(-V, H));
+    }
+    float eta_i = rec.front_face ? 1.0f : mat.ior;
+    float eta_o = rec.front_face ? mat.ior : 1.0f;
+    float eta = eta_i / eta_o;
+    // sample_t
+    V3 H = sample_ggx(mat.roughness, V, rec.normal, seed);
+    float cos_theta = g_min(1.0f, dot(V, H));
+    float sin_theta = g_sqrt(1.0f - cos_theta * cos_theta);
+    bool cannot_refract = eta * sin_theta > 1.0f;
+    float refl = fresnel_dielectric(cos_theta, eta);
+    V3 d;
+    if (cannot_refract || refl > rng_random(seed)) {
+        d = g_reflect(-V, H);
+    } else {
+        d = g_refract(-V, H, eta);
+    }
+    return normalize(d);
+}
+
+// raytracer.comp:789-824
+RT_DEV V3 eval_brdf(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
+    V3 N = rec.normal;
+    float NdotL = dot(L, N);
+    float NdotV = dot(V, N);
+    V3 H = g_sign(NdotV) * normalize(L + V);
+    float VdotH = dot(V, H);
+    float NdotH = dot(N, H);
+
+    float ior_scale = g_mix(0.0f, 2.0f, mat.specular_tint_a);
+    float ri = rec.front_face ? (1.0f / (mat.ior * ior_scale)) : mat.ior * ior_scale;
+    float dielectric_F0 = (1.0f - ri) / (1.0f + ri);
+    V3 dielectric_F0_vec = v3(dielectric_F0 * dielectric_F0);
+    V3 F0 = g_mix(dielectric_F0_vec, mat.albedo, mat.metallic);
+    V3 f_diffuse = mat.albedo / kPi;
+
+    float alpha = mat.roughness * mat.roughness;
+    float D = ggx_distribution(alpha, N, H);
+    float G = G1_GGX(L, N, alpha) * G1_GGX(V, N, alpha);
+    V3 F = reflectance_v(VdotH, F0);
+
+    float ks = g_max(g_max(F.x, F.y), F.z);
+    float kd = (1.0f - ks) * (1.0f - mat.metallic);
+    float jacobian = 1.0f / g_max(0.00001f, 4.0f * NdotV * NdotL);
+    V3 f_specular = mat.specular_tint * D * G * F * jacobian;
+
+    float pdf_specular = g_clamp(D * NdotH * jacobian, 0.0f, 1.0f);
+    float pdf_diffuse = g_clamp(NdotL / kPi, 0.0f, 1.0f);
+    pdf = kd * pdf_diffuse + ks * pdf_specular;
+    return kd * f_diffuse + f_specular;
+}
+
+// raytracer.comp:826-855
+RT_DEV V3 eval_btdf(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
+    L = normalize(L);
+    V = normalize(V);
+    V3 N = normalize(rec.normal);
+    float eta_i = rec.front_face ? 1.0f : mat.ior;
+    float eta_o = rec.front_face ? mat.ior : 1.0f;
+    float eta = eta_i / eta_o;
+    V3 H = -normalize(L + eta * V);
+    float VoH = dot(V, H);
+    float LoH = dot(L, H);
+    float NoH = dot(N, H);
+    float VoN = dot(V, N);
+    float LoN = dot(L, N);
+    float alpha = mat.roughness * mat.roughness;
+    float D = ggx_distribution(alpha, N, H);
+    float G = G1_GGX(L, N, alpha) * G1_GGX(V, N, alpha);
+    float F = fresnel_dielectric(g_abs(VoH), eta);
+    float x = g_abs(VoH) / g_max(0.00001f, g_abs(VoN) * g_abs(LoN));
+    float denom = eta_i * VoH + eta_o * LoH;
+    float jacobian = (eta_o * eta_o * g_abs(LoH)) / g_max(0.00001f, denom * denom);
+    pdf = D * g_abs(NoH) * jacobian;
+    return mat.subsurface * x * jacobian * D * G * (1.0f - F);
+}
+
+// raytracer.comp:859-867
+RT_DEV V3 eval_mat(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
+    L = normalize(L);
+    V3 N = normalize(rec.normal);
+    if (dot(L, N) >= 0.0f) return eval_brdf(mat, L, V, rec, pdf);
+    return eval_btdf(mat, L, V, rec, pdf);
+}
+
+}  // namespace rtd

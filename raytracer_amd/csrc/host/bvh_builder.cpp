@@ -1,0 +1,327 @@
+// bvh_builder.cpp — binned-SAH binary BVH over spheres, triangles and mesh triangles.
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+
+struct Box {
+    float lo[3] = {kInf, kInf, kInf};
+    float hi[3] = {-kInf, -kInf, -kInf};
+    void grow(const float p[3]) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::fmin(lo[k], p[k]);
+            hi[k] = std::fmax(hi[k], p[k]);
+        }
+    }
+    void grow(const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::fmin(lo[k], b.lo[k]);
+            hi[k] = std::fmax(hi[k], b.hi[k]);
+        }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct BuildPrim {
+    Box box;
+    float centroid[3];
+    int32_t flat_index;
+};
+
+// Boxes are padded so that a hit the intersection routine accepts a few ulps outside the
+// exact primitive (rounding in Moeller-Trumbore's u, v, t) still lies inside its leaf box.
+Box padded(const Box& b) {
+    Box r = b;
+    float m = 1.0f;
+    for (int k = 0; k < 3; ++k) m = std::fmax(m, std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    float pad = 1e-4f * m;
+    for (int k = 0; k < 3; ++k) {
+        r.lo[k] = b.lo[k] - pad;
+        r.hi[k] = b.hi[k] + pad;
+    }
+    return r;
+}
+
+Box prim_box(const PrimRecord& p) {
+    Box b;
+    if (p.mat & kSphereFlag) {
+        float r = std::fabs(p.b[0]);
+        float lo[3] = {p.a[0] - r, p.a[1] - r, p.a[2] - r};
+        float hi[3] = {p.a[0] + r, p.a[1] + r, p.a[2] + r};
+        b.grow(lo);
+        b.grow(hi);
+    } else {
+        float v1[3] = {p.a[0] + p.b[0], p.a[1] + p.b[1], p.a[2] + p.b[2]};
+        float v2[3] = {p.a[0] + p.c[0], p.a[1] + p.c[1], p.a[2] + p.c[2]};
+        b.grow(p.a);
+        b.grow(v1);
+        b.grow(v2);
+    }
+    return padded(b);
+}
+
+struct ChildRef {
+    int32_t index;
+    int32_t count;
+    Box box;
+};
+
+class Builder {
+public:
+    Builder(std::vector<BuildPrim>& prims, HostBvh& out) : prims_(prims), out_(out) {}
+
+    static const int kMaxLeaf = 4;
+    static const int kBins = 16;
+
+    ChildRef build(int begin, int end, int depth) {
+        Box box, cbox;
+        for (int i = begin; i < end; ++i) {
+            box.grow(prims_[i].box);
+            cbox.grow(prims_[i].centroid);
+        }
+        int n = end - begin;
+        out_.depth = std::max(out_.depth, depth);
+        if (n <= 1) return leaf(begin, end, box);
+
+        // Levels still available below this node; a subtree of n primitives needs at least
+        // ceil(log2(n / kMaxLeaf)) of them.  When SAH's freedom would risk exceeding the cap,
+        // fall back to splitting the object list in half.
+        int remaining = kMaxBvhDepth - depth;
+        int needed = 0;
+        while (((long long)kMaxLeaf << needed) < n) ++needed;
+        bool force_median = needed + 2 >= remaining;
+
+        int axis = -1;
+        int mid = -1;
+        if (!force_median) {
+            float best_cost = kInf;
+            int best_bin = -1;
+            float parent_area = box.half_area();
+            for (int ax = 0; ax < 3; ++ax) {
+                float lo = cbox.lo[ax], ext = cbox.hi[ax] - cbox.lo[ax];
+                if (!(ext > 0.0f)) continue;
+                Box bin_box[kBins];
+                int bin_cnt[kBins] = {0};
+                float scale = (float)kBins / ext;
+                for (int i = begin; i < end; ++i) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((prims_[i].centroid[ax] - lo) * scale)));
+                    bin_box[b].grow(prims_[i].box);
+                    bin_cnt[b]++;
+                }
+                float right_area[kBins];
+                int right_cnt[kBins];
+                Box acc;
+                int cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_cnt[b];
+                    right_area[b] = acc.half_area();
+                    right_cnt[b] = cnt;
+                }
+                Box accl;
+                int cntl = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    accl.grow(bin_box[b]);
+                    cntl += bin_cnt[b];
+                    if (cntl == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = accl.half_area() * (float)cntl + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_bin = b;
+                        axis = ax;
+                    }
+                }
+            }
+            if (axis >= 0) {
+                // SAH with traversal cost 1 and intersection cost 1 per primitive
+                float split_cost = 1.0f + best_cost / std::fmax(parent_area, 1e-30f);
+                if (n <= kMaxLeaf && (float)n <= split_cost) return leaf(begin, end, box);
+                float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
+                float scale = (float)kBins / ext;
+                auto it = std::partition(prims_.begin() + begin, prims_.begin() + end, [&](const BuildPrim& p) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((p.centroid[axis] - lo) * scale)));
+                    return b <= best_bin;
+                });
+                mid = (int)(it - prims_.begin());
+            } else if (n <= kMaxLeaf) {
+                return leaf(begin, end, box);
+            }
+        } else if (n <= kMaxLeaf) {
+            return leaf(begin, end, box);
+        }
+        if (mid <= begin || mid >= end) {
+            // median split along the widest centroid axis (or by index when all centroids coincide)
+            int ax = 0;
+            float best = -1.0f;
+            for (int k = 0; k < 3; ++k) {
+                float e = cbox.hi[k] - cbox.lo[k];
+                if (e > best) { best = e; ax = k; }
+            }
+            mid = begin + n / 2;
+            std::nth_element(prims_.begin() + begin, prims_.begin() + mid, prims_.begin() + end,
+                             [ax](const BuildPrim& a, const BuildPrim& b) {
+                                 if (a.centroid[ax] != b.centroid[ax]) return a.centroid[ax] < b.centroid[ax];
+                                 return a.flat_index < b.flat_index;
+                             });
+        }
+        int32_t me = (int32_t)out_.nodes.size();
+        out_.nodes.emplace_back();
+        ChildRef l = build(begin, mid, depth + 1);
+        ChildRef r = build(mid, end, depth + 1);
+        set_children(me, l, r);
+        sah_ += box.half_area();
+        ChildRef ref;
+        ref.index = me;
+        ref.count = 0;
+        ref.box = box;
+        return ref;
+    }
+
+    void set_children(int32_t me, const ChildRef& l, const ChildRef& r) {
+        BvhNode& nd = out_.nodes[me];
+        for (int k = 0; k < 3; ++k) {
+            nd.lo0[k] = l.box.lo[k]; nd.hi0[k] = l.box.hi[k];
+            nd.lo1[k] = r.box.lo[k]; nd.hi1[k] = r.box.hi[k];
+        }
+        nd.child0 = l.index; nd.count0 = l.count;
+        nd.child1 = r.index; nd.count1 = r.count;
+    }
+
+    float sah_ = 0.0f;
+    float leaf_sah_ = 0.0f;
+
+private:
+    ChildRef leaf(int begin, int end, const Box& box) {
+        ChildRef ref;
+        ref.index = begin;
+        ref.count = end - begin;
+        ref.box = box;
+        out_.max_leaf = std::max(out_.max_leaf, end - begin);
+        leaf_sah_ += box.half_area() * (float)(end - begin);
+        return ref;
+    }
+    std::vector<BuildPrim>& prims_;
+    HostBvh& out_;
+};
+
+bool fail(std::string* err, const std::string& m) {
+    if (err) *err = m;
+    return false;
+}
+
+}  // namespace
+
+bool gather_primitives(const SceneArrays& s, std::vector<PrimRecord>& out, std::string* err) {
+    out.clear();
+    if (s.n_spheres < 0 || s.n_triangles < 0 || s.n_meshes < 0 || s.n_vertices < 0 || s.n_indices < 0)
+        return fail(err, "negative element count");
+    const int32_t S = s.n_spheres, T = s.n_triangles;
+    for (int32_t i = 0; i < S; ++i) {
+        PrimRecord p;
+        memset(&p, 0, sizeof p);
+        memcpy(p.a, s.spheres[i].pos, 12);
+        p.b[0] = s.spheres[i].r;
+        p.id = i;
+        p.prio = i;
+        p.mat = s.spheres[i].mat | kSphereFlag;
+        out.push_back(p);
+    }
+    for (int32_t i = 0; i < T; ++i) {
+        const RtTriangle& t = s.triangles[i];
+        PrimRecord p;
+        for (int k = 0; k < 3; ++k) {
+            p.a[k] = t.v0[k];
+            p.b[k] = t.v1[k] - t.v0[k];
+            p.c[k] = t.v2[k] - t.v0[k];
+        }
+        p.id = S + i;
+        p.prio = S + i;
+        p.mat = t.mat;
+        out.push_back(p);
+    }
+    for (int32_t m = 0; m < s.n_meshes; ++m) {
+        const RtMeshInfo& mi = s.meshes[m];
+        if (mi.index_end < mi.index_start || (long long)mi.index_end > (long long)s.n_indices)
+            return fail(err, "mesh index range outside the index buffer");
+        // hit_mesh steps i += 3 while i < index_end (raytracer.comp:412); a trailing partial
+        // triple would read past index_end, so only whole triangles are taken.
+        uint32_t ntri = (mi.index_end - mi.index_start) / 3;
+        int32_t first_id = S + T + (int32_t)(mi.index_start / 3);
+        for (uint32_t k = 0; k < ntri; ++k) {
+            uint32_t i = mi.index_start + 3 * k;
+            uint32_t i0 = s.indices[i], i1 = s.indices[i + 1], i2 = s.indices[i + 2];
+            if (i0 >= (uint32_t)s.n_vertices || i1 >= (uint32_t)s.n_vertices || i2 >= (uint32_t)s.n_vertices)
+                return fail(err, "mesh index beyond the vertex buffer");
+            const float* v0 = s.vertices[i0].pos;
+            const float* v1 = s.vertices[i1].pos;
+            const float* v2 = s.vertices[i2].pos;
+            PrimRecord p;
+            for (int c = 0; c < 3; ++c) {
+                p.a[c] = v0[c];
+                p.b[c] = v1[c] - v0[c];
+                p.c[c] = v2[c] - v0[c];
+            }
+            p.id = S + T + (int32_t)(i / 3);
+            // last triangle of the mesh wins ties inside the mesh; earlier meshes win over later ones
+            p.prio = first_id + (int32_t)(ntri - 1 - k);
+            p.mat = mi.material;
+            out.push_back(p);
+        }
+    }
+    return true;
+}
+
+bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
+    out = HostBvh();
+    std::vector<PrimRecord> flat;
+    if (!gather_primitives(s, flat, err)) return false;
+    std::vector<BuildPrim> bp(flat.size());
+    for (size_t i = 0; i < flat.size(); ++i) {
+        bp[i].box = prim_box(flat[i]);
+        for (int k = 0; k < 3; ++k) bp[i].centroid[k] = 0.5f * (bp[i].box.lo[k] + bp[i].box.hi[k]);
+        bp[i].flat_index = (int32_t)i;
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(bp[i].box.lo[k]) || !std::isfinite(bp[i].box.hi[k]))
+                return fail(err, "primitive with non-finite coordinates");
+    }
+    Builder b(bp, out);
+    ChildRef empty;
+    empty.index = -1;
+    empty.count = 0;  // box stays inverted: never entered
+    if (flat.empty()) {
+        out.nodes.emplace_back();
+        b.set_children(0, empty, empty);
+    } else {
+        ChildRef root = b.build(0, (int)bp.size(), 0);
+        if (root.count > 0 || out.nodes.empty()) {
+            // the whole scene fits one leaf: wrap it so that node 0 is always an internal node
+            out.nodes.clear();
+            out.nodes.emplace_back();
+            b.set_children(0, root, empty);
+            out.depth = 1;
+        }
+        Box rb = root.box;
+        float ra = std::fmax(rb.half_area(), 1e-30f);
+        out.sah_cost = (b.sah_ + b.leaf_sah_) / ra;
+    }
+    out.prims.resize(bp.size());
+    out.prim_order.resize(bp.size());
+    for (size_t i = 0; i < bp.size(); ++i) {
+        out.prims[i] = flat[bp[i].flat_index];
+        out.prim_order[i] = bp[i].flat_index;
+    }
+    return true;
+}
+
+}  // namespace rt

@@ -1,0 +1,70 @@
+// bvh_builder.h — host-side construction of the device acceleration structure.
+//
+// The reference has no acceleration structure: hit_scene tests every ray against every
+// sphere, triangle and mesh triangle (shaders/raytracer.comp:469-508).  This builder
+// produces a binary BVH over ALL primitives whose traversal returns the same winner as
+// those flat loops, including their exact-t tie rules:
+//   * across spheres / triangles / meshes the earliest-tested primitive wins
+//     (strict `closest_so_far > t`, raytracer.comp:478,489,500);
+//   * inside one mesh the LAST triangle wins (`t_r > closest_so_far` rejects only larger
+//     t, raytracer.comp:447).
+// Both rules are folded into one integer `prio` per primitive: lower prio wins a tie.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_abi.h"
+
+namespace rt {
+
+struct SceneArrays {
+    const RtSphere* spheres = nullptr;     int32_t n_spheres = 0;
+    const RtTriangle* triangles = nullptr; int32_t n_triangles = 0;
+    const RtVertex* vertices = nullptr;    int32_t n_vertices = 0;
+    const uint32_t* indices = nullptr;     int32_t n_indices = 0;
+    const RtMeshInfo* meshes = nullptr;    int32_t n_meshes = 0;
+};
+
+// One primitive as the kernels read it: 48 bytes, three 16-byte loads.
+//   triangle: a = v0, b = v1 - v0, c = v2 - v0 (the edges the shader forms at
+//             raytracer.comp:368-369 / 417-418, same binary32 subtraction)
+//   sphere:   a = centre, b.x = radius
+struct PrimRecord {
+    float a[3];
+    int32_t id;    // global primitive id: spheres [0,S), triangles [S,S+T), mesh triangles S+T+index/3
+    float b[3];
+    int32_t prio;  // tie-break key, lower wins
+    float c[3];
+    int32_t mat;   // material index; bit 31 set marks a sphere record
+};
+static_assert(sizeof(PrimRecord) == 48, "PrimRecord must be 48 bytes");
+static const int32_t kSphereFlag = (int32_t)0x80000000u;
+
+// Binary node holding BOTH children's boxes (64 bytes, four 16-byte loads).
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;  // count == 0: index of an internal node; count > 0: first PrimRecord of a leaf
+    int32_t count0, count1;  // primitives in the leaf (0 for an internal child)
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+struct HostBvh {
+    std::vector<BvhNode> nodes;         // nodes[0] is the root
+    std::vector<PrimRecord> prims;      // leaf order
+    std::vector<int32_t> prim_order;    // prims[i] came from flat-order primitive prim_order[i]
+    int32_t depth = 0;                  // deepest leaf (root children are at depth 1)
+    float sah_cost = 0.0f;
+    int32_t max_leaf = 0;
+};
+
+// Flat-order primitive records (the order the reference's loops test them in): spheres,
+// triangles, then each mesh's triangles.  Used by the flat kernel and as builder input.
+bool gather_primitives(const SceneArrays& s, std::vector<PrimRecord>& out, std::string* err);
+
+static const int kMaxBvhDepth = 30;  // traversal stacks hold kMaxBvhDepth + 2 entries
+
+bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err);
+
+}  // namespace rt

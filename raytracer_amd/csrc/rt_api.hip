@@ -1,0 +1,436 @@
+// rt_api.hip — device half of the C ABI in include/rt_abi.h: the context that owns the
+// hipMalloc'd scene / framebuffer memory and launches the kernels.  It stands where the
+// reference's Vulkan buffer, descriptor and dispatch code stands (src/main.cpp:1222-1306,
+// 1424-1606); each entry point cites its counterpart in the header.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "device/rt_kernels.h"
+#include "host/bvh_builder.h"
+#include "host/scene_handle.h"
+
+struct RtContext {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+
+    // scene
+    bool has_scene = false;
+    void* d_prims_bvh = nullptr;
+    void* d_prims_flat = nullptr;
+    void* d_nodes = nullptr;
+    void* d_materials = nullptr;
+    void* d_lights = nullptr;
+    void* d_triangles = nullptr;
+    int32_t n_prims = 0, n_spheres = 0, n_triangles = 0, n_meshes = 0, n_lights = 0, n_materials = 0;
+    int32_t bvh_nodes = 0, bvh_depth = 0;
+
+    // framebuffer
+    int32_t width = 0, height = 0;
+    bool owns_fb = false;
+    void* d_accum = nullptr;
+    void* d_counts = nullptr;
+    void* d_bgra = nullptr;
+    int32_t* d_primary_ids = nullptr;
+    uint32_t* d_path_hash = nullptr;
+    uint32_t* d_counters = nullptr;  // 8 x u32, see FrameArgs::counters
+
+    std::string err;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(RtContext* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail((ctx), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+void free_scene(RtContext* c) {
+    void** ptrs[] = {&c->d_prims_bvh, &c->d_prims_flat, &c->d_nodes, &c->d_materials, &c->d_lights, &c->d_triangles};
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->has_scene = false;
+}
+
+void free_framebuffer(RtContext* c) {
+    if (c->owns_fb) {
+        if (c->d_accum) (void)hipFree(c->d_accum);
+        if (c->d_counts) (void)hipFree(c->d_counts);
+        if (c->d_bgra) (void)hipFree(c->d_bgra);
+    }
+    if (c->d_primary_ids) (void)hipFree(c->d_primary_ids);
+    if (c->d_path_hash) (void)hipFree(c->d_path_hash);
+    c->d_accum = c->d_counts = c->d_bgra = nullptr;
+    c->d_primary_ids = nullptr;
+    c->d_path_hash = nullptr;
+    c->owns_fb = false;
+    c->width = c->height = 0;
+}
+
+// hipMalloc max(bytes, min_bytes), zero it, copy `bytes` from src.
+int upload_array(RtContext* c, void** dst, const void* src, size_t bytes, size_t min_bytes) {
+    size_t alloc = bytes > min_bytes ? bytes : min_bytes;
+    RT_HIP(c, hipMalloc(dst, alloc));
+    RT_HIP(c, hipMemsetAsync(*dst, 0, alloc, c->stream));
+    if (bytes) RT_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+int alloc_debug_buffers(RtContext* c) {
+    size_t n = (size_t)c->width * (size_t)c->height;
+    if (!c->d_primary_ids) {
+        RT_HIP(c, hipMalloc((void**)&c->d_primary_ids, n * 4));
+        RT_HIP(c, hipMemsetAsync(c->d_primary_ids, 0xff, n * 4, c->stream));
+    }
+    if (!c->d_path_hash) {
+        RT_HIP(c, hipMalloc((void**)&c->d_path_hash, n * 4));
+        RT_HIP(c, hipMemsetAsync(c->d_path_hash, 0, n * 4, c->stream));
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(int device_ordinal, RtContext** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    RT_HIP(nullptr, hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    RT_HIP(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, RT_ERR_UNSUPPORTED,
+                    std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 (MI355X) code only");
+    RtContext* c = new (std::nothrow) RtContext();
+    if (!c) return fail(nullptr, RT_ERR_TOO_LARGE, "out of host memory");
+    c->device = device_ordinal;
+    c->cu_count = prop.multiProcessorCount;
+    hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e2 = hipEventCreate(&c->ev_begin);
+    hipError_t e3 = hipEventCreate(&c->ev_end);
+    hipError_t e4 = hipMalloc((void**)&c->d_counters, 32);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        rt_destroy(c);
+        return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
+    }
+    *out_ctx = c;
+    return RT_OK;
+}
+
+int rt_destroy(RtContext* c) {
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_framebuffer(c);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, const RtMaterial* materials,
+                    int32_t n_materials, const RtLight* lights, int32_t n_lights, const RtTriangle* triangles,
+                    int32_t n_triangles, const RtVertex* vertices, int32_t n_vertices, const uint32_t* indices,
+                    int32_t n_indices, const RtMeshInfo* meshes, int32_t n_meshes) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (n_spheres < 0 || n_materials < 0 || n_lights < 0 || n_triangles < 0 || n_vertices < 0 || n_indices < 0 || n_meshes < 0)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "negative element count");
+    if ((n_spheres && !spheres) || (n_materials && !materials) || (n_lights && !lights) || (n_triangles && !triangles) ||
+        (n_vertices && !vertices) || (n_indices && !indices) || (n_meshes && !meshes))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    // The kernels index materials / triangles / vertices with values taken from the scene:
+    // check every such index on the host so that no launch can read out of bounds.
+    for (int32_t i = 0; i < n_spheres; ++i)
+        if (spheres[i].mat < 0 || spheres[i].mat >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "sphere material index out of range");
+    for (int32_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].mat < 0 || triangles[i].mat >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "triangle material index out of range");
+    for (int32_t i = 0; i < n_meshes; ++i)
+        if (meshes[i].material < 0 || meshes[i].material >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh material index out of range");
+    for (int32_t i = 0; i < n_lights; ++i) {
+        if (lights[i].type == RT_LIGHT_TRIANGLE) {
+            float fx = lights[i].pos_angle_aux[0];
+            if (!(fx >= 0.0f) || !(fx < (float)(n_triangles > 0 ? n_triangles : 1)))
+                return fail(c, RT_ERR_INVALID_ARGUMENT, "TRIANGLE light refers to a triangle that does not exist");
+        }
+    }
+    rt::SceneArrays a;
+    a.spheres = spheres;     a.n_spheres = n_spheres;
+    a.triangles = triangles; a.n_triangles = n_triangles;
+    a.vertices = vertices;   a.n_vertices = n_vertices;
+    a.indices = indices;     a.n_indices = n_indices;
+    a.meshes = meshes;       a.n_meshes = n_meshes;
+    std::vector<rt::PrimRecord> flat;
+    std::string err;
+    if (!rt::gather_primitives(a, flat, &err)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
+    if (flat.size() >= (size_t)(1u << 28)) return fail(c, RT_ERR_TOO_LARGE, "more than 2^28 primitives");
+    rt::HostBvh bvh;
+    if (!rt::build_bvh(a, bvh, &err)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
+    if (bvh.depth > rt::kMaxBvhDepth || bvh.max_leaf > 8) return fail(c, RT_ERR_TOO_LARGE, "BVH exceeds traversal limits");
+
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    int rc;
+    if ((rc = upload_array(c, &c->d_prims_bvh, bvh.prims.data(), bvh.prims.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_prims_flat, flat.data(), flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_materials, materials, (size_t)n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_lights, lights, (size_t)n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_triangles, triangles, (size_t)n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // host vectors above go out of scope
+    c->n_prims = (int32_t)flat.size();
+    c->n_spheres = n_spheres;
+    c->n_triangles = n_triangles;
+    c->n_meshes = n_meshes;
+    c->n_lights = n_lights;
+    c->n_materials = n_materials;
+    c->bvh_nodes = (int32_t)bvh.nodes.size();
+    c->bvh_depth = bvh.depth;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int rt_upload_scene_from(RtContext* c, const RtScene* s) {
+    if (!c || !s) return RT_ERR_INVALID_ARGUMENT;
+    const rt::Scene& sc = s->scene;
+    return rt_upload_scene(c, sc.sphereVec.data(), sc.total_spheres, sc.materialVec.data(), (int32_t)sc.materialVec.size(),
+                           sc.lightsVec.data(), sc.total_lights, sc.triangleVec.data(), sc.total_triangles,
+                           sc.vertexVec.data(), (int32_t)sc.vertexVec.size(), sc.indexVec.data(),
+                           (int32_t)sc.indexVec.size(), sc.meshVec.data(), sc.total_meshes);
+}
+
+int rt_resize(RtContext* c, int32_t width, int32_t height) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "bad image size");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_framebuffer(c);
+    size_t n = (size_t)width * (size_t)height;
+    c->owns_fb = true;
+    RT_HIP(c, hipMalloc(&c->d_accum, n * 16));
+    RT_HIP(c, hipMalloc(&c->d_counts, n * 4));
+    RT_HIP(c, hipMalloc(&c->d_bgra, n * 4));
+    RT_HIP(c, hipMemsetAsync(c->d_accum, 0, n * 16, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counts, 0, n * 4, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_bgra, 0, n * 4, c->stream));
+    c->width = width;
+    c->height = height;
+    return RT_OK;
+}
+
+int rt_bind_framebuffer(RtContext* c, int32_t width, int32_t height, void* d_accum, void* d_counts, void* d_bgra) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28) || !d_accum || !d_counts || !d_bgra)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "bad framebuffer binding");
+    if (((uintptr_t)d_accum & 15u) || ((uintptr_t)d_counts & 3u) || ((uintptr_t)d_bgra & 3u))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "framebuffer pointers must be 16/4/4-byte aligned");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_framebuffer(c);
+    c->owns_fb = false;
+    c->d_accum = d_accum;
+    c->d_counts = d_counts;
+    c->d_bgra = d_bgra;
+    c->width = width;
+    c->height = height;
+    return RT_OK;
+}
+
+int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!camera || !pc) return fail(c, RT_ERR_INVALID_ARGUMENT, "camera / push constants are null");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (!c->d_accum) return fail(c, RT_ERR_NO_FRAMEBUFFER, "rt_resize / rt_bind_framebuffer has not been called");
+    RtParams p;
+    if (params) p = *params; else rt_default_params(&p);
+    if (p.spp <= 0 || p.max_bounces < 0 || p.spp > 65536 || p.max_bounces > 65536)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "spp / max_bounces out of range");
+    if (p.accel != RT_ACCEL_FLAT && p.accel != RT_ACCEL_BVH) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown accel");
+    if (p.strip_rows > 0 && (p.strip_count < 1 || p.strip_index < 0 || p.strip_index >= p.strip_count))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "bad strip partition");
+    // The acceleration structure was built for the uploaded element counts; the loop bounds
+    // the shader would take from the push constants must be those counts.
+    if (pc->total_spheres != c->n_spheres || pc->total_triangles != c->n_triangles || pc->total_meshes != c->n_meshes)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "push-constant primitive counts differ from the uploaded scene");
+    if (pc->total_lights < 0 || pc->total_lights > c->n_lights)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "push-constant light count exceeds the uploaded lights");
+
+    rtd::DeviceScene sc;
+    sc.prims_bvh = (const float4*)c->d_prims_bvh;
+    sc.prims_flat = (const float4*)c->d_prims_flat;
+    sc.nodes = (const float4*)c->d_nodes;
+    sc.materials = (const float4*)c->d_materials;
+    sc.lights = (const float4*)c->d_lights;
+    sc.triangles = (const float4*)c->d_triangles;
+    sc.n_prims = c->n_prims;
+    sc.n_spheres = c->n_spheres;
+    sc.n_triangles = c->n_triangles;
+
+    rtd::FrameArgs fa;
+    memcpy(fa.view_inv, camera->viewInv, 64);
+    memcpy(fa.cam_pos, camera->position, 12);
+    fa.tan_half_fov = camera->tanHalfFOV;
+    // uint(pc.time): GLSL leaves negative / out-of-range conversions undefined; they map to 0 here
+    fa.time_u = (pc->time >= 0.0f && pc->time < 4294967296.0f) ? (uint32_t)pc->time : 0u;
+    fa.frame_count = pc->frameCount;
+    fa.total_lights = pc->total_lights;
+    fa.lights_strength_sum = pc->lights_strength_sum;
+    fa.reset = pc->reset_frame_accumulation ? 1u : 0u;
+    fa.width = c->width;
+    fa.height = c->height;
+    fa.spp = p.spp;
+    fa.max_bounces = p.max_bounces;
+    fa.strip_rows = p.strip_rows > 0 ? p.strip_rows : 0;
+    fa.strip_count = p.strip_rows > 0 ? p.strip_count : 1;
+    fa.strip_index = p.strip_rows > 0 ? p.strip_index : 0;
+    int owned = c->height;
+    if (p.strip_rows > 0) {
+        owned = 0;
+        int n_strips = (c->height + p.strip_rows - 1) / p.strip_rows;
+        for (int s = p.strip_index; s < n_strips; s += p.strip_count) {
+            int rows = c->height - s * p.strip_rows;
+            owned += rows < p.strip_rows ? rows : p.strip_rows;
+        }
+    }
+    fa.owned_rows = owned;
+    fa.tiles_x = (c->width + 7) / 8;
+    fa.total_slots = (uint32_t)fa.tiles_x * (uint32_t)((owned + 7) / 8) * 64u;
+    fa.flags = p.flags;
+    fa.accum = (float4*)c->d_accum;
+    fa.counts = (int32_t*)c->d_counts;
+    fa.bgra = (uint32_t*)c->d_bgra;
+    fa.primary_ids = nullptr;
+    fa.path_hash = nullptr;
+    fa.counters = c->d_counters;
+
+    RT_HIP(c, hipSetDevice(c->device));
+    if (p.flags & (RT_FLAG_PRIMARY_IDS | RT_FLAG_PATH_HASH)) {
+        int rc = alloc_debug_buffers(c);
+        if (rc != RT_OK) return rc;
+        if (p.flags & RT_FLAG_PRIMARY_IDS) fa.primary_ids = c->d_primary_ids;
+        if (p.flags & RT_FLAG_PATH_HASH) fa.path_hash = c->d_path_hash;
+    }
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
+    if (fa.total_slots > 0) {
+        // Persistent grid: at most four 256-thread workgroups per CU (the LDS traversal stacks
+        // of four workgroups fill 128 of the CU's 160 KiB), fewer when the image is small.
+        long long want = ((long long)fa.total_slots + rtd::kBlock - 1) / rtd::kBlock;
+        long long cap = (long long)c->cu_count * 4;
+        int grid = (int)(want < cap ? want : cap);
+        bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
+        RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, grid, c->stream));
+    }
+    RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
+    c->timed = true;
+    return RT_OK;
+}
+
+int rt_resolve(RtContext* c) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->d_accum) return fail(c, RT_ERR_NO_FRAMEBUFFER, "no framebuffer");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, rtd::launch_resolve((float4*)c->d_accum, (int32_t*)c->d_counts, (uint32_t*)c->d_bgra, c->width * c->height,
+                                  c->stream));
+    return RT_OK;
+}
+
+int rt_read_output_bgra8(RtContext* c, void* dst) {
+    if (!c || !dst) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->d_bgra) return fail(c, RT_ERR_NO_FRAMEBUFFER, "no framebuffer");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(dst, c->d_bgra, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_read_accum(RtContext* c, float* accum, int32_t* counts) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->d_accum) return fail(c, RT_ERR_NO_FRAMEBUFFER, "no framebuffer");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    size_t n = (size_t)c->width * c->height;
+    if (accum) RT_HIP(c, hipMemcpy(accum, c->d_accum, n * 16, hipMemcpyDeviceToHost));
+    if (counts) RT_HIP(c, hipMemcpy(counts, c->d_counts, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_read_debug(RtContext* c, int32_t* primary_ids, uint32_t* path_hash) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if ((primary_ids && !c->d_primary_ids) || (path_hash && !c->d_path_hash))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "no frame was rendered with RT_FLAG_PRIMARY_IDS / RT_FLAG_PATH_HASH");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    size_t n = (size_t)c->width * c->height;
+    if (primary_ids) RT_HIP(c, hipMemcpy(primary_ids, c->d_primary_ids, n * 4, hipMemcpyDeviceToHost));
+    if (path_hash) RT_HIP(c, hipMemcpy(path_hash, c->d_path_hash, n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_stats(RtContext* c, RtStats* out) {
+    if (!c || !out) return RT_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof *out);
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t h[8] = {0};
+    RT_HIP(c, hipMemcpy(h, c->d_counters, 32, hipMemcpyDeviceToHost));
+    memcpy(&out->rays, &h[2], 8);
+    memcpy(&out->nodes_visited, &h[4], 8);
+    memcpy(&out->prims_tested, &h[6], 8);
+    if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
+    out->bvh_nodes = c->bvh_nodes;
+    out->bvh_depth = c->bvh_depth;
+    out->total_prims = c->n_prims;
+    return RT_OK;
+}
+
+int rt_get_device_buffers(RtContext* c, void** d_accum, void** d_counts, void** d_bgra8) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->d_accum) return fail(c, RT_ERR_NO_FRAMEBUFFER, "no framebuffer");
+    if (d_accum) *d_accum = c->d_accum;
+    if (d_counts) *d_counts = c->d_counts;
+    if (d_bgra8) *d_bgra8 = c->d_bgra;
+    return RT_OK;
+}
+
+void* rt_get_stream(RtContext* c) { return c ? (void*)c->stream : nullptr; }
+
+int rt_sync(RtContext* c) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+const char* rt_last_error(RtContext* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
