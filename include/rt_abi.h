@@ -201,6 +201,12 @@ int rt_read_accum(RtContext* ctx, float* accum_float4, int32_t* counts);
  * mesh triangles S+T+index/3) and the per-pixel path hash.  Either may be NULL. */
 int rt_read_debug(RtContext* ctx, int32_t* primary_ids, uint32_t* path_hash);
 
+/* Self-test hook with no counterpart in the reference: evaluates one of the device's
+ * arithmetic primitives element-wise (fn: 0 sin, 1 cos, 2 tan, 3 acos, 4 pow(x,y), 5 log2,
+ * 6 exp2, 7 asin, 8 x/y, 9 sqrt, 10 random() from state bits x, 11 x*y+x, 12 1/sqrt(x*x+y*y)).
+ * x, y, out are HOST arrays of n floats. */
+int rt_debug_math(RtContext* ctx, int fn, const float* x, const float* y, float* out, int32_t n);
+
 int rt_get_stats(RtContext* ctx, RtStats* out);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);

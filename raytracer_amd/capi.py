@@ -122,6 +122,7 @@ PROTOTYPES = {
     "rt_read_output_bgra8": (C.c_int, [_P, _P]),
     "rt_read_accum": (C.c_int, [_P, _P, _P]),
     "rt_read_debug": (C.c_int, [_P, _P, _P]),
+    "rt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int32]),
     "rt_get_stats": (C.c_int, [_P, C.POINTER(RtStats)]),
     "rt_get_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "rt_get_stream": (_P, [_P]),

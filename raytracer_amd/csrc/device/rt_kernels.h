@@ -52,6 +52,7 @@ enum { kBlock = 256, kStackDepth = 32 };
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int grid_blocks,
                          hipStream_t stream);
+hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);
 
 }  // namespace rtd

@@ -483,7 +483,39 @@ __global__ void __launch_bounds__(256) resolve_kernel(const float4* __restrict__
     if (i < n) bgra[i] = resolve_pixel(accum[i], counts[i]);
 }
 
+// Evaluates one arithmetic primitive of rt_math.h per element (self-test of the contract
+// that the device reproduces a host binary32 evaluation bit for bit).
+__global__ void __launch_bounds__(256) math_probe_kernel(int fn, const float* __restrict__ x, const float* __restrict__ y,
+                                                         float* __restrict__ out, int n) {
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    float a = x[i], b = y[i], r = 0.0f;
+    switch (fn) {
+        case 0: r = g_sin(a); break;
+        case 1: r = g_cos(a); break;
+        case 2: r = g_tan(a); break;
+        case 3: r = g_acos(a); break;
+        case 4: r = g_pow(a, b); break;
+        case 5: r = g_log2(a); break;
+        case 6: r = g_exp2(a); break;
+        case 7: r = g_asin(a); break;
+        case 8: r = a / b; break;
+        case 9: r = g_sqrt(a); break;
+        case 10: { uint32_t s = __float_as_uint(a); r = rng_random(s); } break;
+        case 11: r = a * b + a; break;       // must stay two roundings (no contraction)
+        case 12: r = 1.0f / g_sqrt(a * a + b * b); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
 }  // namespace
+
+hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, x, y, out, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int grid_blocks,
                          hipStream_t stream) {

@@ -29,7 +29,7 @@ RT_DEV float g_clamp(float x, float lo, float hi) { return g_min(g_max(x, lo), h
 RT_DEV float g_abs(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 RT_DEV float g_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 RT_DEV float g_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
-RT_DEV float g_sqrt(float x) { return __fsqrt_rn(x); }
+RT_DEV float g_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE sqrt under -fhip-fp32-correctly-rounded-divide-sqrt
 
 // ---- trigonometry: Cody-Waite reduction by pi/4 octants + minimax polynomials ----------
 static constexpr float kFOPI = 1.27323954473516f;

@@ -422,6 +422,27 @@ int rt_get_device_buffers(RtContext* c, void** d_accum, void** d_counts, void** 
     return RT_OK;
 }
 
+int rt_debug_math(RtContext* c, int fn, const float* x, const float* y, float* out, int32_t n) {
+    if (!c || !x || !y || !out || n < 0) return RT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RT_OK;
+    RT_HIP(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)n * 4;
+    hipError_t e = hipMalloc((void**)&dx, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&dy, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rtd::launch_math_probe(fn, dx, dy, dout, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_debug_math: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
 void* rt_get_stream(RtContext* c) { return c ? (void*)c->stream : nullptr; }
 
 int rt_sync(RtContext* c) {

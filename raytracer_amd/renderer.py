@@ -207,6 +207,14 @@ class Context:
                   "rt_read_debug")
         return ids, ph
 
+    def debug_math(self, fn: int, x: np.ndarray, y: Optional[np.ndarray] = None) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+        out = np.empty_like(x)
+        self._chk(self._lib.rt_debug_math(self._h, int(fn), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p), int(x.size)), "rt_debug_math")
+        return out
+
     def stats(self) -> capi.RtStats:
         st = capi.RtStats()
         self._chk(self._lib.rt_get_stats(self._h, C.byref(st)), "rt_get_stats")

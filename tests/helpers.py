@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests: run the same frames through the CPU oracle and
+through the HIP library (C ABI) and compare."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_binding as ob
+from raytracer_amd import capi
+from raytracer_amd.renderer import Context, Scene, default_camera, make_params
+
+DEBUG_FLAGS = capi.RT_FLAG_PRIMARY_IDS | capi.RT_FLAG_PATH_HASH
+
+
+def oracle_frames(scene: Scene, width, height, spp, max_bounces, frames=1, math_mode=0, camera=None, time=0.0,
+                  threads=8, strip=(0, 1, 0)):
+    cam = camera or default_camera(width, height)
+    osc = ob.OracleScene(scene.arrays())
+    acc = cnt = None
+    total_rays = 0
+    out = None
+    for f in range(frames):
+        pc = scene.push_constants(time, f, f == 0)
+        out = ob.render(osc, cam, pc, width, height, spp, max_bounces, math_mode=math_mode, threads=threads, accum=acc,
+                        counts=cnt, strip=strip)
+        acc, cnt = out["accum"], out["counts"]
+        total_rays += out["rays"]
+    out["total_rays"] = total_rays
+    return out
+
+
+def gpu_frames(ctx: Context, scene: Scene, width, height, spp, max_bounces, frames=1, accel=capi.RT_ACCEL_BVH,
+               camera=None, time=0.0, flags=DEBUG_FLAGS, strip=(0, 1, 0), upload=True, resize=True):
+    cam = camera or default_camera(width, height)
+    if upload:
+        ctx.upload_scene(scene)
+    if resize:
+        ctx.resize(width, height)
+    total_rays = 0
+    for f in range(frames):
+        pc = scene.push_constants(time, f, f == 0)
+        p = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags)
+        ctx.render_frame(cam, pc, p)
+        total_rays += ctx.stats().rays
+    acc, cnt = ctx.read_accum()
+    ids, ph = ctx.read_debug() if flags & DEBUG_FLAGS else (None, None)
+    return {"accum": acc, "counts": cnt, "bgra": ctx.read_bgra8(), "primary_ids": ids, "path_hash": ph,
+            "total_rays": total_rays, "stats": ctx.stats()}
+
+
+def bit_equal_pixels(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Per-pixel mask: every float of the pixel has the same bit pattern."""
+    ua = np.ascontiguousarray(a).view(np.uint32)
+    ub = np.ascontiguousarray(b).view(np.uint32)
+    eq = ua == ub
+    return eq.all(axis=-1) if eq.ndim == 3 else eq
