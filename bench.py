@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one frame (one execution of the reference shader's main() per pixel) of the
+workload BASELINE.json's metric is quoted on: Cornell box + teapot.glb, 1920x1080, 16
+samples per pixel, 4 bounces.  At N > 1 (launched by torch.distributed.run, one rank per
+GPU) the frame is split into row strips, the scene is replicated, and the frame is
+completed on every rank by an RCCL all-gather; the total work is fixed, so scaling is
+"strong".  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracer_amd import capi, parallel  # noqa: E402
+from raytracer_amd.renderer import Context, Scene, default_camera, look_camera, make_params  # noqa: E402
+
+WORKLOADS = {
+    # name: (scene preset, width, height, spp, max_bounces, description)
+    "c3": (capi.RT_SCENE_CORNELL_TEAPOT, 1920, 1080, 16, 4,
+           "Cornell box + teapot.glb (6360 primitives), 1920x1080, 16 spp, 4 bounces"),
+    "c2": (capi.RT_SCENE_CORNELL_STAR, 1920, 1080, 4, 20,
+           "reference default scene (Cornell box + star.glb, 100 primitives), 1920x1080, 4 spp, 20 bounces"),
+    "c5": (capi.RT_SCENE_TEAPOT_GRID, 1920, 1080, 8, 20,
+           "13x13 teapot grid (1 068 084 primitives), 1920x1080, 8 spp, 20 bounces"),
+}
+STRIP_ROWS = 9  # 1080 / 9 = 120 strips: divisible by 1, 2, 4 and 8 ranks
+
+# MI355X vector FP32 peak (spec): 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
+PEAK_VALU_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
+
+
+def cpu_baseline(scene: Scene, max_bounces: int) -> dict:
+    """The CPU oracle (flat search = the reference's algorithm) on a bounded sample of the
+    same scene and camera: 160x90 pixels, 1 spp."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    w, h, spp = 160, 90, 1
+    threads = max(1, min(16, os.cpu_count() or 1))
+    cam = default_camera(w, h)
+    osc = ob.OracleScene(scene.arrays())
+    pc = scene.push_constants(0.0, 0, True)
+    t0 = time.perf_counter()
+    out = ob.render(osc, cam, pc, w, h, spp, max_bounces, threads=threads, want_debug=False)
+    dt = time.perf_counter() - t0
+    return {"value": out["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene and camera at {w}x{h}, {spp} spp, {max_bounces} bounces, flat search "
+                      f"(every ray x every primitive, as the reference shader), {out['rays']} rays in {dt:.2f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--accel", default="bvh", choices=["bvh", "flat"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    preset, W, H, spp, max_bounces, desc = WORKLOADS[args.workload]
+    accel = capi.RT_ACCEL_BVH if args.accel == "bvh" else capi.RT_ACCEL_FLAT
+    scene = Scene(preset)
+    ctx = Context(local_rank)
+    ctx.upload_scene(scene)
+    # framebuffer in torch tensors so that RCCL reads the library's output in place
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    bgra = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.bind_framebuffer(W, H, acc.data_ptr(), cnt.data_ptr(), bgra.data_ptr())
+    if args.workload == "c5":
+        cam = look_camera((3.0, 7.0, -9.0), (0.0, -0.38, 1.0), (0.0, 1.0, 0.0), 50.0, W, H)
+    else:
+        cam = default_camera(W, H)
+    strip = (STRIP_ROWS, world, rank) if world > 1 else (0, 1, 0)
+    params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
+    rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    main_stream = torch.cuda.current_stream(dev)
+
+    def step(frame: int, ev=None) -> None:
+        pc = scene.push_constants(0.0, frame, frame == 0)
+        if ev is not None:
+            ev[0].record(rt_stream)
+        ctx.render_frame(cam, pc, params)
+        if ev is not None:
+            ev[1].record(rt_stream)
+        if world > 1:
+            main_stream.wait_stream(rt_stream)
+            parallel.gather_strips([acc, cnt, bgra], H, STRIP_ROWS, world, rank)
+            rt_stream.wait_stream(main_stream)
+
+    def fence() -> None:
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for f in range(args.warmup):
+        step(f)
+    fence()
+    rays0 = ctx.stats().total_rays
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, events[k])
+    fence()
+    t1 = time.perf_counter()
+    rays = ctx.stats().total_rays - rays0
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+    kern = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total_rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kern, op=dist.ReduceOp.MAX)
+    elapsed_s = float(elapsed.item())
+    job_rays = float(total_rays.item())
+    avg_kernel_ms = float(kern.item())
+
+    # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
+    flags = capi.RT_FLAG_TRAVERSAL_STATS
+    pc = scene.push_constants(0.0, args.warmup, False)
+    ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
+    st = ctx.stats()
+    nodes_per_ray = st.nodes_visited / max(1, st.rays)
+    tests_per_ray = st.prims_tested / max(1, st.rays)
+
+    if rank == 0:
+        v = scene.view()
+        n_prims = st.total_prims
+        pixels_per_launch = W * H / world
+        rays_per_launch = job_rays / args.steps / world
+        if accel == capi.RT_ACCEL_BVH:
+            # per ray: 2 box tests (24 flop each) per visited node, 51 flop per triangle test;
+            # 64 B per visited node, 48 B per tested primitive record; + 48 B framebuffer per pixel
+            flops_per_ray = 24.0 * 2.0 * nodes_per_ray + 51.0 * tests_per_ray
+            bytes_per_ray = 64.0 * nodes_per_ray + 48.0 * tests_per_ray
+        else:
+            flops_per_ray = 30.0 * v.total_spheres + 51.0 * (n_prims - v.total_spheres)
+            bytes_per_ray = 48.0 * n_prims
+        launch_flops = flops_per_ray * rays_per_launch
+        launch_bytes = bytes_per_ray * rays_per_launch + 48.0 * pixels_per_launch
+        achieved_tflops = launch_flops / (avg_kernel_ms * 1e-3) / 1e12
+        result = {
+            "metric": "Mrays/s",
+            "value": job_rays / elapsed_s / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_s / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "search": args.accel,
+                       "partition": f"row strips of {STRIP_ROWS} rows, all-gather" if world > 1 else "single GPU",
+                       "rays_per_frame": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
+            "roofline": {
+                "bound": "valu",
+                "kernel": "render_kernel",
+                "achieved": achieved_tflops,
+                "peak": PEAK_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_VALU_TFLOPS,
+                "traffic": None,
+                "avg_kernel_ms": avg_kernel_ms,
+                "flops_per_ray": flops_per_ray,
+                "bytes_per_ray": bytes_per_ray,
+                "nodes_per_ray": nodes_per_ray,
+                "prim_tests_per_ray": tests_per_ray,
+                "algorithmic_GBps": launch_bytes / (avg_kernel_ms * 1e-3) / 1e9,
+                "hbm_peak_GBps": PEAK_HBM_GBPS,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, max_bounces)
+        print(json.dumps(result), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,13 +132,14 @@ typedef struct RtParams {
 
 enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id per pixel       */
        RT_FLAG_PATH_HASH   = 2u,   /* record a hash of every nearest-hit id along the paths    */
-       RT_FLAG_COUNT_RAYS  = 4u,   /* count nearest-hit searches (1 ray = 1 hit_scene call)    */
+       RT_FLAG_COUNT_RAYS  = 4u,   /* accepted, no effect: rays are always counted             */
        RT_FLAG_TRAVERSAL_STATS = 8u /* count BVH nodes visited / primitives tested             */ };
 
 typedef struct RtStats {
-    uint64_t rays;          /* nearest-hit searches in the last frame (needs COUNT_RAYS)       */
+    uint64_t rays;          /* nearest-hit searches in the last frame (always counted)         */
     uint64_t nodes_visited; /* BVH nodes whose children were box-tested (needs TRAVERSAL_STATS)*/
     uint64_t prims_tested;  /* primitive intersection tests (needs TRAVERSAL_STATS)            */
+    uint64_t total_rays;    /* nearest-hit searches of ALL frames since rt_create              */
     float    kernel_ms;     /* HIP-event time of the last frame's render kernel                */
     int32_t  bvh_nodes;     /* nodes in the device BVH                                         */
     int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */

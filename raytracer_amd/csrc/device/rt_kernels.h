@@ -45,6 +45,7 @@ struct FrameArgs {
     int32_t* primary_ids;  // may be null
     uint32_t* path_hash;   // may be null
     // device counters: [0] next pixel slot, [2..3] rays (u64), [4..5] nodes visited, [6..7] prims tested
+    // (cleared per frame), [8..9] rays of all frames (never cleared)
     uint32_t* counters;
 };
 

@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
     }
     if (lane == 0) {
         atomicAdd((unsigned long long*)(fa.counters + 2), r);
+        atomicAdd((unsigned long long*)(fa.counters + 8), r);
         if (STATS) {
             atomicAdd((unsigned long long*)(fa.counters + 4), nn);
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);

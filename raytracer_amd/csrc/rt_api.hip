@@ -41,7 +41,7 @@ struct RtContext {
     void* d_bgra = nullptr;
     int32_t* d_primary_ids = nullptr;
     uint32_t* d_path_hash = nullptr;
-    uint32_t* d_counters = nullptr;  // 8 x u32, see FrameArgs::counters
+    uint32_t* d_counters = nullptr;  // 16 x u32, see FrameArgs::counters
 
     std::string err;
 };
@@ -133,7 +133,8 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev_begin);
     hipError_t e3 = hipEventCreate(&c->ev_end);
-    hipError_t e4 = hipMalloc((void**)&c->d_counters, 32);
+    hipError_t e4 = hipMalloc((void**)&c->d_counters, 64);
+    if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 64);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
@@ -401,11 +402,12 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memset(out, 0, sizeof *out);
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t h[8] = {0};
-    RT_HIP(c, hipMemcpy(h, c->d_counters, 32, hipMemcpyDeviceToHost));
+    uint32_t h[16] = {0};
+    RT_HIP(c, hipMemcpy(h, c->d_counters, 64, hipMemcpyDeviceToHost));
     memcpy(&out->rays, &h[2], 8);
     memcpy(&out->nodes_visited, &h[4], 8);
     memcpy(&out->prims_tested, &h[6], 8);
+    memcpy(&out->total_rays, &h[8], 8);
     if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;
