@@ -267,7 +267,9 @@ int rt_camera_default(RtCamera* out, int32_t width, int32_t height);
 int rt_push_constants(RtPushConstants* out, const RtScene* s, float time, uint32_t frame_count,
                       int reset_accumulation);
 
-/* Host BVH statistics for a scene (no GPU needed): node count, depth, SAH cost. */
+/* Builds the host BVH of a scene (no GPU needed), checks its structure (every primitive in
+ * exactly one leaf, boxes nested, depth within the traversal limit; RT_ERR_UNSUPPORTED if
+ * not) and reports node count, depth, primitive count and SAH cost. */
 int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost);
 
 #ifdef __cplusplus

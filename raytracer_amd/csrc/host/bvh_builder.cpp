@@ -324,4 +324,65 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
     return true;
 }
 
+bool validate_bvh(const HostBvh& bvh, std::string* err) {
+    if (bvh.nodes.empty()) return fail(err, "no root node");
+    std::vector<int> node_seen(bvh.nodes.size(), 0), prim_seen(bvh.prims.size(), 0);
+    struct Item { int32_t child, count; Box box; int depth; };
+    std::vector<Item> stack;
+    auto child_items = [&](const BvhNode& n, int depth, Item out[2]) {
+        for (int k = 0; k < 3; ++k) {
+            out[0].box.lo[k] = n.lo0[k]; out[0].box.hi[k] = n.hi0[k];
+            out[1].box.lo[k] = n.lo1[k]; out[1].box.hi[k] = n.hi1[k];
+        }
+        out[0].child = n.child0; out[0].count = n.count0; out[0].depth = depth;
+        out[1].child = n.child1; out[1].count = n.count1; out[1].depth = depth;
+    };
+    auto inside = [](const Box& inner, const Box& outer) {
+        for (int k = 0; k < 3; ++k)
+            if (inner.lo[k] < outer.lo[k] || inner.hi[k] > outer.hi[k]) return false;
+        return true;
+    };
+    Item it[2];
+    node_seen[0] = 1;
+    child_items(bvh.nodes[0], 1, it);
+    stack.push_back(it[0]);
+    stack.push_back(it[1]);
+    int max_depth = 0;
+    while (!stack.empty()) {
+        Item cur = stack.back();
+        stack.pop_back();
+        if (cur.count == 0 && cur.child < 0) continue;  // empty slot
+        max_depth = std::max(max_depth, cur.depth);
+        if (cur.depth > kMaxBvhDepth) return fail(err, "BVH deeper than the traversal stack allows");
+        if (cur.count > 0) {
+            if (cur.count > 8 || cur.child < 0 || (size_t)cur.child + (size_t)cur.count > bvh.prims.size())
+                return fail(err, "leaf range out of bounds");
+            for (int k = 0; k < cur.count; ++k) {
+                if (prim_seen[cur.child + k]++) return fail(err, "primitive referenced by two leaves");
+                Box pb = prim_box(bvh.prims[cur.child + k]);
+                if (!inside(pb, cur.box)) return fail(err, "leaf box does not contain its primitive");
+            }
+        } else {
+            if ((size_t)cur.child >= bvh.nodes.size()) return fail(err, "child index out of bounds");
+            if (node_seen[cur.child]++) return fail(err, "node reachable twice");
+            child_items(bvh.nodes[cur.child], cur.depth + 1, it);
+            for (int c = 0; c < 2; ++c) {
+                if (it[c].count == 0 && it[c].child < 0) continue;
+                if (!inside(it[c].box, cur.box)) return fail(err, "child box not inside its parent's box");
+                stack.push_back(it[c]);
+            }
+        }
+    }
+    for (size_t i = 0; i < prim_seen.size(); ++i)
+        if (prim_seen[i] != 1) return fail(err, "primitive missing from the leaves");
+    for (size_t i = 0; i < node_seen.size(); ++i)
+        if (node_seen[i] != 1) return fail(err, "unreachable node");
+    std::vector<int> order_seen(bvh.prims.size(), 0);
+    for (int32_t o : bvh.prim_order) {
+        if (o < 0 || (size_t)o >= order_seen.size() || order_seen[o]++) return fail(err, "prim_order is not a permutation");
+    }
+    (void)max_depth;
+    return true;
+}
+
 }  // namespace rt

@@ -67,4 +67,9 @@ static const int kMaxBvhDepth = 30;  // traversal stacks hold kMaxBvhDepth + 2 e
 
 bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err);
 
+// Structural self-check: every node reachable exactly once, every primitive in exactly one
+// leaf, every leaf box contains its primitives, every stored child box contains the boxes
+// stored below it, depth and leaf size within the traversal kernel's limits.
+bool validate_bvh(const HostBvh& bvh, std::string* err);
+
 }  // namespace rt

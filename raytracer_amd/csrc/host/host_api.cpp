@@ -180,6 +180,7 @@ int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_
     rt::HostBvh bvh;
     std::string err;
     if (!rt::build_bvh(a, bvh, &err)) return RT_ERR_INVALID_ARGUMENT;
+    if (!rt::validate_bvh(bvh, &err)) return RT_ERR_UNSUPPORTED;
     if (n_nodes) *n_nodes = (int32_t)bvh.nodes.size();
     if (depth) *depth = bvh.depth;
     if (n_prims) *n_prims = (int32_t)bvh.prim_order.size();

@@ -1,0 +1,46 @@
+"""The C-ABI library loads without a GPU and exports every function include/rt_abi.h declares;
+the ctypes mirror covers all of them.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+from raytracer_amd import capi
+
+HEADER = os.path.join(capi.REPO_ROOT, "include", "rt_abi.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in rt_abi.h but not exported"
+
+
+def test_ctypes_mirror_covers_the_header():
+    assert sorted(capi.PROTOTYPES) == declared_functions()
+
+
+def test_struct_sizes_match_the_shader_layouts():
+    assert C.sizeof(capi.RtSphere) == 32 and C.sizeof(capi.RtTriangle) == 64 and C.sizeof(capi.RtVertex) == 16
+    assert C.sizeof(capi.RtMaterial) == 80 and C.sizeof(capi.RtLight) == 48 and C.sizeof(capi.RtMeshInfo) == 12
+    assert C.sizeof(capi.RtCamera) == 336 and C.sizeof(capi.RtPushConstants) == 44
+    assert capi.RtCamera.viewInv.offset == 64 and capi.RtCamera.position.offset == 320 and capi.RtCamera.tanHalfFOV.offset == 332
+    assert capi.RtPushConstants.reset_frame_accumulation.offset == 28 and capi.RtPushConstants.total_meshes.offset == 40
+    assert capi.RtTriangle.normal.offset == 48 and capi.RtTriangle.mat.offset == 60
+
+
+def test_defaults_and_errors_without_gpu():
+    lib = capi.load()
+    p = capi.RtParams()
+    lib.rt_default_params(C.byref(p))
+    assert (p.spp, p.max_bounces, p.accel) == (5, 20, capi.RT_ACCEL_BVH)  # raytracer.comp:117-118
+    assert lib.rt_abi_version() == 1
+    assert lib.rt_render_frame(None, None, None, None) == capi.RT_ERR_INVALID_ARGUMENT
+    assert lib.rt_scene_create(99, None, C.byref(C.c_void_p())) == capi.RT_ERR_INVALID_ARGUMENT
