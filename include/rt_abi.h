@@ -140,6 +140,12 @@ typedef struct RtStats {
     uint64_t nodes_visited; /* BVH nodes whose children were box-tested (needs TRAVERSAL_STATS)*/
     uint64_t prims_tested;  /* primitive intersection tests (needs TRAVERSAL_STATS)            */
     uint64_t total_rays;    /* nearest-hit searches of ALL frames since rt_create              */
+    /* the next five need TRAVERSAL_STATS (instrumented kernel, never the timed one):           */
+    uint64_t cycles_raygen; /* wave cycles spent in pixel refill + ray generation              */
+    uint64_t cycles_search; /* wave cycles spent in the nearest-hit search                     */
+    uint64_t cycles_shade;  /* wave cycles spent in the continuation (lights, BSDF, store)     */
+    uint64_t lane_iterations; /* traversal loop iterations summed over lanes                   */
+    uint64_t wave_iterations; /* traversal loop iterations summed over waves (slowest lane)    */
     float    kernel_ms;     /* HIP-event time of the last frame's render kernel                */
     int32_t  bvh_nodes;     /* nodes in the device BVH                                         */
     int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */

@@ -90,7 +90,9 @@ class RtParams(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("total_rays", C.c_uint64), ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
+                ("total_rays", C.c_uint64), ("cycles_raygen", C.c_uint64), ("cycles_search", C.c_uint64),
+                ("cycles_shade", C.c_uint64), ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
+                ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
                 ("total_prims", C.c_int32)]
 
 

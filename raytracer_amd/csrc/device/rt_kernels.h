@@ -38,6 +38,7 @@ struct FrameArgs {
     int32_t tiles_x;                                // ceil(width / 8)
     uint32_t total_slots;                           // tiles_x * ceil(owned_rows / 8) * 64
     uint32_t flags;
+    int32_t exit_quota_pct;  // the search loop returns once this share of the wave's busy lanes has finished
     // outputs
     float4* accum;
     int32_t* counts;
@@ -45,7 +46,9 @@ struct FrameArgs {
     int32_t* primary_ids;  // may be null
     uint32_t* path_hash;   // may be null
     // device counters: [0] next pixel slot, [2..3] rays (u64), [4..5] nodes visited, [6..7] prims tested
-    // (cleared per frame), [8..9] rays of all frames (never cleared)
+    // (cleared per frame), [8..9] rays of all frames (never cleared); instrumented builds only (cleared
+    // per frame): [10..15] wave cycles in refill+raygen / search / shading, [16..17] per-lane traversal
+    // iterations, [18..19] per-wave traversal iterations (longest lane of each search)
     uint32_t* counters;
 };
 

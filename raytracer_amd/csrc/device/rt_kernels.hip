@@ -70,15 +70,41 @@ RT_DEV void trace_flat(const DeviceScene& sc, V3 ro, V3 rd, float& best_t, int& 
     for (int i = 0; i < sc.n_prims; ++i) intersect_record(sc.prims_flat, i, ro, rd, best_t, best_prio, best_idx);
 }
 
-// Stack entries: >= 0 internal node index; < 0 a leaf: bit 31 | (count-1) << 28 | first record.
+// Traversal cursor of one lane: >= 0 an internal node index (below kTravDone); < 0 a leaf,
+// bit 31 | (count-1) << 28 | first record; kTravDone when the search has finished.
+static constexpr int kTravDone = 0x7fffffff;
 RT_DEV int encode_child(int child, int count) { return count > 0 ? (int)(0x80000000u | ((uint32_t)(count - 1) << 28) | (uint32_t)child) : child; }
 
-// Binary BVH, both child boxes in the parent, per-lane stack in LDS (column `tid` of a
-// [depth][block] array: lane-private, bank = tid mod 32 at every depth, so no conflicts).
+struct Trav {
+    int cur;        // cursor (see above)
+    int sp;         // entries on this lane's LDS stack
+    float best_t;   // winner so far
+    int best_prio;
+    int best_idx;   // record index of the winner, -1 = none
+};
+
+RT_DEV void trav_pop(Trav& tv, const uint32_t* __restrict__ stack) {
+    if (tv.sp == 0) {
+        tv.cur = kTravDone;
+    } else {
+        tv.sp--;
+        tv.cur = (int)stack[tv.sp * kBlock];
+    }
+}
+
+// Resumable nearest-hit search over the binary BVH (both child boxes in the parent; per-lane
+// stack in LDS: column `tid` of a [depth][block] array, lane-private, bank = tid mod 32 at
+// every depth, so conflict-free).  Each loop iteration the wave votes (ballot + popcount)
+// for ONE kind of step — visit an internal node, or test one leaf primitive — and only the
+// lanes whose cursor is of that kind take it; the minority waits a step instead of dragging
+// the whole wave through both code paths.  The loop returns as soon as `exit_quota` lanes
+// have finished (or none is left), so that finished lanes go on to shading and to their
+// next ray while the stragglers keep their cursor, stack and best hit and resume on the
+// next call: a long traversal no longer holds 63 idle lanes hostage.
 template <bool STATS>
-RT_DEV void trace_bvh(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, float& best_t, int& best_idx,
-                      uint32_t& n_nodes, uint32_t& n_tests) {
-    int best_prio = 0x7fffffff;
+RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, Trav& tv, bool wants_result,
+                            int exit_quota, uint32_t& n_nodes, uint32_t& n_tests, uint32_t& n_iters,
+                            unsigned long long& wave_iters) {
     // Slab arithmetic runs on a direction with no zero component; the boxes are padded on
     // the host by far more than the half-ulp origin perturbation the fused form implies.
     float dx = (g_abs(rd.x) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.x) : rd.x;
@@ -88,52 +114,59 @@ RT_DEV void trace_bvh(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict_
     const float ox = -(ro.x * ix), oy = -(ro.y * iy), oz = -(ro.z * iz);
     const float4* __restrict__ nodes = sc.nodes;
 
-    int sp = 0;
-    int cur = 0;  // node 0 is always internal
     for (;;) {
-        if (cur >= 0) {
-            const float4 q0 = nodes[4 * cur + 0];
-            const float4 q1 = nodes[4 * cur + 1];
-            const float4 q2 = nodes[4 * cur + 2];
-            const float4 q3 = nodes[4 * cur + 3];
-            if (STATS) n_nodes++;
-            // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-            float a0 = __builtin_fmaf(q0.x, ix, ox), b0 = __builtin_fmaf(q0.w, ix, ox);
-            float a1 = __builtin_fmaf(q0.y, iy, oy), b1 = __builtin_fmaf(q1.x, iy, oy);
-            float a2 = __builtin_fmaf(q0.z, iz, oz), b2 = __builtin_fmaf(q1.y, iz, oz);
-            float tmin0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), 0.0f));
-            float tmax0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), best_t));
-            float c0 = __builtin_fmaf(q1.z, ix, ox), d0 = __builtin_fmaf(q2.y, ix, ox);
-            float c1 = __builtin_fmaf(q1.w, iy, oy), d1 = __builtin_fmaf(q2.z, iy, oy);
-            float c2 = __builtin_fmaf(q2.x, iz, oz), d2 = __builtin_fmaf(q2.w, iz, oz);
-            float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
-            float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), best_t));
-            const bool hit0 = tmin0 <= tmax0 * 1.0000005f;
-            const bool hit1 = tmin1 <= tmax1 * 1.0000005f;
-            int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
-            int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
-            if (hit0 && hit1) {
-                if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
-                stack[sp * kBlock] = (uint32_t)r1;
-                sp++;
-                cur = r0;
-            } else if (hit0) {
-                cur = r0;
-            } else if (hit1) {
-                cur = r1;
-            } else {
-                if (sp == 0) break;
-                sp--;
-                cur = (int)stack[sp * kBlock];
+        const unsigned long long m_node = __ballot(tv.cur >= 0 && tv.cur != kTravDone);
+        const unsigned long long m_leaf = __ballot(tv.cur < 0);
+        if ((m_node | m_leaf) == 0ull) break;
+        const unsigned long long m_done = __ballot(wants_result && tv.cur == kTravDone);
+        if (__popcll(m_done) >= exit_quota) break;
+        if (STATS) wave_iters++;
+        if (__popcll(m_node) >= __popcll(m_leaf)) {
+            if (tv.cur >= 0 && tv.cur != kTravDone) {
+                const float4 q0 = nodes[4 * tv.cur + 0];
+                const float4 q1 = nodes[4 * tv.cur + 1];
+                const float4 q2 = nodes[4 * tv.cur + 2];
+                const float4 q3 = nodes[4 * tv.cur + 3];
+                if (STATS) { n_nodes++; n_iters++; }
+                // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+                float a0 = __builtin_fmaf(q0.x, ix, ox), b0 = __builtin_fmaf(q0.w, ix, ox);
+                float a1 = __builtin_fmaf(q0.y, iy, oy), b1 = __builtin_fmaf(q1.x, iy, oy);
+                float a2 = __builtin_fmaf(q0.z, iz, oz), b2 = __builtin_fmaf(q1.y, iz, oz);
+                float tmin0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), 0.0f));
+                float tmax0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tv.best_t));
+                float c0 = __builtin_fmaf(q1.z, ix, ox), d0 = __builtin_fmaf(q2.y, ix, ox);
+                float c1 = __builtin_fmaf(q1.w, iy, oy), d1 = __builtin_fmaf(q2.z, iy, oy);
+                float c2 = __builtin_fmaf(q2.x, iz, oz), d2 = __builtin_fmaf(q2.w, iz, oz);
+                float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
+                float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), tv.best_t));
+                // an unused child slot (child index -1, inverted box) must never be entered: the slab
+                // arithmetic on its infinities would report a hit
+                const bool hit0 = (tmin0 <= tmax0 * 1.0000005f) && (__float_as_int(q3.x) >= 0);
+                const bool hit1 = (tmin1 <= tmax1 * 1.0000005f) && (__float_as_int(q3.y) >= 0);
+                int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
+                int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
+                if (hit0 && hit1) {
+                    if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
+                    stack[tv.sp * kBlock] = (uint32_t)r1;
+                    tv.sp++;
+                    tv.cur = r0;
+                } else if (hit0) {
+                    tv.cur = r0;
+                } else if (hit1) {
+                    tv.cur = r1;
+                } else {
+                    trav_pop(tv, stack);
+                }
             }
         } else {
-            const int first = cur & 0x0fffffff;
-            const int count = ((cur >> 28) & 7) + 1;
-            for (int k = 0; k < count; ++k) intersect_record(sc.prims_bvh, first + k, ro, rd, best_t, best_prio, best_idx);
-            if (STATS) n_tests += (uint32_t)count;
-            if (sp == 0) break;
-            sp--;
-            cur = (int)stack[sp * kBlock];
+            if (tv.cur < 0) {
+                const int first = tv.cur & 0x0fffffff;
+                const int left = (tv.cur >> 28) & 7;  // primitives after this one
+                intersect_record(sc.prims_bvh, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
+                if (STATS) { n_tests++; n_iters++; }
+                if (left == 0) trav_pop(tv, stack);
+                else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 1) << 28) | (uint32_t)(first + 1));
+            }
         }
     }
 }
@@ -200,14 +233,21 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
     float s_d = 0.0f;
     int s_light = 0;
     // counters
-    uint32_t n_rays = 0, n_nodes = 0, n_tests = 0;
+    uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, n_iters = 0;
+    unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, wave_iters = 0;  // STATS only
     // wave-uniform pixel reserve
     uint32_t res_next = 0, res_left = 0;
     bool exhausted = false;
+    // resumable search state; `fresh` marks a ray (qo, qd) whose search has not started yet
+    Trav tv;
+    tv.cur = kTravDone; tv.sp = 0; tv.best_t = kInf; tv.best_prio = 0x7fffffff; tv.best_idx = -1;
+    bool fresh = false;
 
     const float aspect = (float)fa.width / (float)fa.height;  // raytracer.comp:187
 
     for (;;) {
+        long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+        if (STATS) stamp0 = (long long)__builtin_readcyclecounter();
         // ------------------------------------------------------------------ refill idle lanes
         const unsigned long long idle = __ballot(state == ST_IDLE);
         if (idle != 0ull) {
@@ -272,6 +312,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             col = v3(0.0f);
             bounce = 0;
             state = ST_TRACE_PATH;
+            fresh = true;
         }
 
         if (__ballot(state != ST_IDLE) == 0ull) {
@@ -279,28 +320,42 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             continue;
         }
 
-        // ------------------------------------------------------------------ nearest-hit search (all busy lanes together)
-        float hit_t = kInf;
-        int hit_idx = -1;
-        if (state != ST_IDLE) {
+        // ------------------------------------------------------------------ nearest-hit search
+        if (STATS) stamp1 = (long long)__builtin_readcyclecounter();
+        if (state != ST_IDLE && fresh) {
+            fresh = false;
             n_rays++;
-            if (ACCEL == 1) {
-                trace_bvh<STATS>(sc, qo, qd, &s_stack[tid], hit_t, hit_idx, n_nodes, n_tests);
-            } else {
-                trace_flat(sc, qo, qd, hit_t, hit_idx);
+            tv.cur = (ACCEL == 1) ? 0 : kTravDone;  // node 0 is always an internal node
+            tv.sp = 0;
+            tv.best_t = kInf;
+            tv.best_prio = 0x7fffffff;
+            tv.best_idx = -1;
+            if (ACCEL != 1) {
+                trace_flat(sc, qo, qd, tv.best_t, tv.best_idx);
                 if (STATS) n_tests += (uint32_t)sc.n_prims;
             }
         }
-
+        if (ACCEL == 1) {
+            // leave the loop once half of the wave's busy lanes have a result to shade
+            const int busy_lanes = __popcll(__ballot(state != ST_IDLE));
+            int quota = (busy_lanes * fa.exit_quota_pct + 99) / 100;
+            quota = quota < 1 ? 1 : quota;
+            trace_bvh_steps<STATS>(sc, qo, qd, &s_stack[tid], tv, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
+        }
+        if (STATS) stamp2 = (long long)__builtin_readcyclecounter();
+        // lanes whose search is still running keep their state and skip the continuation
+        const bool ready = (state != ST_IDLE) && (tv.cur == kTravDone);
+        const float hit_t = tv.best_t;
+        const int hit_idx = tv.best_idx;
         // ------------------------------------------------------------------ continuation
         bool need_shade = false, have_direct = false, end_sample = false;
         Hit h = sh;
-        const bool is_primary = (state == ST_TRACE_PATH && sample == 0 && bounce == 0);
+        const bool is_primary = (ready && state == ST_TRACE_PATH && sample == 0 && bounce == 0);
         V3 Le = v3(0.0f), Ldir = v3(0.0f);
         float light_pdf = 0.0f;
         int prim_id = -1;
 
-        if (state == ST_TRACE_LIGHT) {
+        if (ready && state == ST_TRACE_LIGHT) {
             // second half of sample_light (raytracer.comp:617-626, 636-644, 662-671)
             if (hit_idx >= 0) prim_id = __float_as_int(recs[3 * hit_idx].w);
             const float4 lc = sc.lights[3 * s_light + 1];
@@ -321,7 +376,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             }
             have_direct = true;
             need_shade = true;
-        } else if (state == ST_TRACE_PATH) {
+        } else if (ready && state == ST_TRACE_PATH) {
             if (hit_idx < 0) {
                 col = col + att * v3(0.3f);  // skybox_color_grey, raytracer.comp:570-577, 924
                 end_sample = true;
@@ -331,6 +386,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
                 if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
                     ro = h.p;
                     qo = ro;
+                    fresh = true;
                     bounce++;
                     if (bounce > fa.max_bounces) end_sample = true;
                 } else if (mat.emission_a > 0.0f) {  // raytracer.comp:901-904
@@ -396,6 +452,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
                             s_light = low;
                             qo = h.p;
                             qd = s_L;
+                            fresh = true;
                             state = ST_TRACE_LIGHT;
                             need_shade = false;
                         }
@@ -406,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             }
         }
         if (is_primary && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[py * fa.width + px] = prim_id;
-        if (state != ST_IDLE) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
+        if (ready) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
         if (need_shade) {
             const Material mat = load_material(sc.materials, h.mat);
@@ -428,6 +485,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             rd = bounce_dir;
             qo = ro;
             qd = rd;
+            fresh = true;
             bounce++;
             state = ST_TRACE_PATH;
             if (bounce > fa.max_bounces) end_sample = true;
@@ -457,15 +515,22 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
                 state = ST_IDLE;
             }
         }
+        if (STATS) {
+            long long stamp3 = (long long)__builtin_readcyclecounter();
+            cyc_gen += (unsigned long long)(stamp1 - stamp0);
+            cyc_trace += (unsigned long long)(stamp2 - stamp1);
+            cyc_shade += (unsigned long long)(stamp3 - stamp2);
+        }
     }
 
     // ---- counters: one atomic per wave
-    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests;
+    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests, ni = n_iters;
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_down(r, off);
         if (STATS) {
             nn += __shfl_down(nn, off);
             nt += __shfl_down(nt, off);
+            ni += __shfl_down(ni, off);
         }
     }
     if (lane == 0) {
@@ -474,6 +539,11 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
         if (STATS) {
             atomicAdd((unsigned long long*)(fa.counters + 4), nn);
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);
+            atomicAdd((unsigned long long*)(fa.counters + 10), cyc_gen);
+            atomicAdd((unsigned long long*)(fa.counters + 12), cyc_trace);
+            atomicAdd((unsigned long long*)(fa.counters + 14), cyc_shade);
+            atomicAdd((unsigned long long*)(fa.counters + 16), ni);
+            atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
         }
     }
 }

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -81,7 +82,11 @@ class Builder {
 public:
     Builder(std::vector<BuildPrim>& prims, HostBvh& out) : prims_(prims), out_(out) {}
 
-    static const int kMaxLeaf = 4;
+    static int max_leaf() {
+        static int v = [] { const char* e = getenv("RT_MAX_LEAF"); int x = e ? atoi(e) : 4; return (x >= 1 && x <= 8) ? x : 4; }();
+        return v;
+    }
+#define kMaxLeaf max_leaf()
     static const int kBins = 16;
 
     ChildRef build(int begin, int end, int depth) {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,7 +42,7 @@ struct RtContext {
     void* d_bgra = nullptr;
     int32_t* d_primary_ids = nullptr;
     uint32_t* d_path_hash = nullptr;
-    uint32_t* d_counters = nullptr;  // 16 x u32, see FrameArgs::counters
+    uint32_t* d_counters = nullptr;  // 32 x u32, see FrameArgs::counters
 
     std::string err;
 };
@@ -133,8 +134,8 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev_begin);
     hipError_t e3 = hipEventCreate(&c->ev_end);
-    hipError_t e4 = hipMalloc((void**)&c->d_counters, 64);
-    if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 64);
+    hipError_t e4 = hipMalloc((void**)&c->d_counters, 128);
+    if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 128);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
@@ -326,6 +327,11 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     fa.tiles_x = (c->width + 7) / 8;
     fa.total_slots = (uint32_t)fa.tiles_x * (uint32_t)((owned + 7) / 8) * 64u;
     fa.flags = p.flags;
+    fa.exit_quota_pct = 75;
+    if (const char* q = getenv("RT_EXIT_QUOTA_PCT")) {  // tuning aid
+        int v = atoi(q);
+        if (v >= 1 && v <= 100) fa.exit_quota_pct = v;
+    }
     fa.accum = (float4*)c->d_accum;
     fa.counts = (int32_t*)c->d_counts;
     fa.bgra = (uint32_t*)c->d_bgra;
@@ -341,6 +347,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (p.flags & RT_FLAG_PATH_HASH) fa.path_hash = c->d_path_hash;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 88, c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     if (fa.total_slots > 0) {
         // Persistent grid: at most four 256-thread workgroups per CU (the LDS traversal stacks
@@ -402,12 +409,17 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memset(out, 0, sizeof *out);
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t h[16] = {0};
-    RT_HIP(c, hipMemcpy(h, c->d_counters, 64, hipMemcpyDeviceToHost));
+    uint32_t h[32] = {0};
+    RT_HIP(c, hipMemcpy(h, c->d_counters, 128, hipMemcpyDeviceToHost));
     memcpy(&out->rays, &h[2], 8);
     memcpy(&out->nodes_visited, &h[4], 8);
     memcpy(&out->prims_tested, &h[6], 8);
     memcpy(&out->total_rays, &h[8], 8);
+    memcpy(&out->cycles_raygen, &h[10], 8);
+    memcpy(&out->cycles_search, &h[12], 8);
+    memcpy(&out->cycles_shade, &h[14], 8);
+    memcpy(&out->lane_iterations, &h[16], 8);
+    memcpy(&out->wave_iterations, &h[18], 8);
     if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;

@@ -93,6 +93,8 @@ class Scene:
         v = self.view()
 
         def grab(ptr, n, size):
+            if n == 0 or not ptr:
+                return np.zeros(0, np.uint8)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * size,)).copy()
 
         return {

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Instrumented frame: where the render kernel's wave cycles go and how full the waves are
+in the traversal loop.  python tools/phase_stats.py [c2|c3|c5]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd import capi
+from raytracer_amd.renderer import Context, Scene, default_camera, look_camera, make_params
+W = {"c3": (capi.RT_SCENE_CORNELL_TEAPOT, 16, 4), "c2": (capi.RT_SCENE_CORNELL_STAR, 4, 20), "c5": (capi.RT_SCENE_TEAPOT_GRID, 8, 20)}
+name = sys.argv[1] if len(sys.argv) > 1 else "c3"
+preset, spp, mb = W[name]
+s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(1920, 1080)
+cam = look_camera((3.0, 7.0, -9.0), (0.0, -0.38, 1.0), (0.0, 1.0, 0.0), 50.0, 1920, 1080) if name == "c5" else default_camera(1920, 1080)
+for flags in (0, 0, capi.RT_FLAG_TRAVERSAL_STATS):
+    ctx.render_frame(cam, s.push_constants(0.0, 1, True), make_params(spp, mb, capi.RT_ACCEL_BVH, flags=flags))
+    st = ctx.stats()
+    print(f"flags={flags} kernel_ms={st.kernel_ms:.3f} rays={st.rays} Mrays/s={st.rays/st.kernel_ms/1e3:.1f}")
+tot = st.cycles_raygen + st.cycles_search + st.cycles_shade
+print(f"nodes/ray={st.nodes_visited/st.rays:.2f} tests/ray={st.prims_tested/st.rays:.2f}")
+print(f"wave cycles: raygen {st.cycles_raygen/tot:.3f} search {st.cycles_search/tot:.3f} shade {st.cycles_shade/tot:.3f}")
+print(f"traversal lane occupancy: {st.lane_iterations/(64*max(1,st.wave_iterations)):.3f} (lane iters {st.lane_iterations}, wave iters {st.wave_iterations})")
