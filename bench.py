@@ -45,11 +45,11 @@ PEAK_HBM_GBPS = 8000.0
 
 def cpu_baseline(scene: Scene, max_bounces: int) -> dict:
     """The CPU oracle (flat search = the reference's algorithm) on a bounded sample of the
-    same scene and camera: 160x90 pixels, 1 spp."""
+    same scene and camera: 640x360 pixels, 1 spp (about 30 s of single-core work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    w, h, spp = 160, 90, 1
+    w, h, spp = 640, 360, 1
     threads = max(1, min(16, os.cpu_count() or 1))
     cam = default_camera(w, h)
     osc = ob.OracleScene(scene.arrays())
@@ -70,6 +70,8 @@ def main() -> None:
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--accel", default="bvh", choices=["bvh", "flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,7 +83,10 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     preset, W, H, spp, max_bounces, desc = WORKLOADS[args.workload]
@@ -99,7 +104,7 @@ def main() -> None:
         cam = look_camera((3.0, 7.0, -9.0), (0.0, -0.38, 1.0), (0.0, 1.0, 0.0), 50.0, W, H)
     else:
         cam = default_camera(W, H)
-    strip = (STRIP_ROWS, world, rank) if world > 1 else (0, 1, 0)
+    strip = (STRIP_ROWS, world, rank) if collective else (0, 1, 0)
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     main_stream = torch.cuda.current_stream(dev)
@@ -111,15 +116,15 @@ def main() -> None:
         ctx.render_frame(cam, pc, params)
         if ev is not None:
             ev[1].record(rt_stream)
-        if world > 1:
+        if collective:
             main_stream.wait_stream(rt_stream)
-            parallel.gather_strips([acc, cnt, bgra], H, STRIP_ROWS, world, rank)
+            parallel.gather_strips([acc, cnt, bgra], H, STRIP_ROWS, world, rank, force=args.force_collective)
             rt_stream.wait_stream(main_stream)
 
     def fence() -> None:
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -139,7 +144,7 @@ def main() -> None:
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
     kern = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collective:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(kern, op=dist.ReduceOp.MAX)
@@ -185,7 +190,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "search": args.accel,
-                       "partition": f"row strips of {STRIP_ROWS} rows, all-gather" if world > 1 else "single GPU",
+                       "partition": f"row strips of {STRIP_ROWS} rows, all-gather" if collective else "single GPU",
                        "rays_per_frame": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
             "roofline": {
                 "bound": "valu",
@@ -209,7 +214,7 @@ def main() -> None:
         print(json.dumps(result), flush=True)
 
     ctx.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

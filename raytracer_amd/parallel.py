@@ -30,10 +30,11 @@ def strip_rows_of(height: int, strip_rows: int, world: int, rank: int) -> torch.
 
 
 def gather_strips(buffers: List[torch.Tensor], height: int, strip_rows: int, world: int, rank: int,
-                  group: Optional[dist.ProcessGroup] = None) -> None:
+                  group: Optional[dist.ProcessGroup] = None, force: bool = False) -> None:
     """Complete full-frame `buffers` (each shaped [height, ...], only this rank's rows
-    valid) in place with the rows of every other rank."""
-    if world <= 1:
+    valid) in place with the rows of every other rank.  `force` runs the pack / all-gather
+    / unpack even for a single rank (a self-test of the collective path)."""
+    if world <= 1 and not force:
         return
     rows = [strip_rows_of(height, strip_rows, world, r) for r in range(world)]
     max_rows = max(int(r.numel()) for r in rows)
@@ -45,7 +46,7 @@ def gather_strips(buffers: List[torch.Tensor], height: int, strip_rows: int, wor
         recv = torch.empty((world, max_rows) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
         dist.all_gather_into_tensor(recv.view(world * max_rows, *buf.shape[1:]), send, group=group)
         for r in range(world):
-            if r == rank:
+            if r == rank and not force:
                 continue
             idx = rows[r].to(buf.device)
             buf.index_copy_(0, idx, recv[r, : idx.numel()])
