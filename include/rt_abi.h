@@ -145,7 +145,9 @@ typedef struct RtStats {
     uint64_t cycles_search; /* wave cycles spent in the nearest-hit search                     */
     uint64_t cycles_shade;  /* wave cycles spent in the continuation (lights, BSDF, store)     */
     uint64_t lane_iterations; /* traversal loop iterations summed over lanes                   */
-    uint64_t wave_iterations; /* traversal loop iterations summed over waves (slowest lane)    */
+    uint64_t wave_iterations; /* traversal loop iterations summed over waves                   */
+    uint64_t cycles_shade_parts[5]; /* cycles_shade split: hit record + light pick, direct BSDF,
+                                       direction sampling, indirect BSDF, sample/pixel end      */
     float    kernel_ms;     /* HIP-event time of the last frame's render kernel                */
     int32_t  bvh_nodes;     /* nodes in the device BVH                                         */
     int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */

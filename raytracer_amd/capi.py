@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraytracer_amd.so")
+# RT_LIB_PATH: load another build of the same ABI (A/B timing of two builds on one device)
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "lib", "libraytracer_amd.so")
 REPO_ROOT = os.path.dirname(_HERE)
 ASSETS_DIR = os.path.join(REPO_ROOT, "assets") + os.sep
 
@@ -92,6 +93,7 @@ class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
                 ("total_rays", C.c_uint64), ("cycles_raygen", C.c_uint64), ("cycles_search", C.c_uint64),
                 ("cycles_shade", C.c_uint64), ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
+                ("cycles_shade_parts", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
                 ("total_prims", C.c_int32)]
 

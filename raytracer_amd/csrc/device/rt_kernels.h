@@ -48,13 +48,14 @@ struct FrameArgs {
     // device counters: [0] next pixel slot, [2..3] rays (u64), [4..5] nodes visited, [6..7] prims tested
     // (cleared per frame), [8..9] rays of all frames (never cleared); instrumented builds only (cleared
     // per frame): [10..15] wave cycles in refill+raygen / search / shading, [16..17] per-lane traversal
-    // iterations, [18..19] per-wave traversal iterations (longest lane of each search)
+    // iterations, [18..19] per-wave traversal iterations, [20..29] wave cycles of the five parts of
+    // the continuation
     uint32_t* counters;
 };
 
 enum { kBlock = 256, kStackDepth = 32 };
 
-hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int grid_blocks,
+hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
                          hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);

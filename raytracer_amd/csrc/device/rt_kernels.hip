@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
     // counters
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, n_iters = 0;
     unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, wave_iters = 0;  // STATS only
+    unsigned long long cyc_part[5] = {0, 0, 0, 0, 0};  // continuation: hit+light pick, direct BSDF, sampling, indirect BSDF, sample end
     // wave-uniform pixel reserve
     uint32_t res_next = 0, res_left = 0;
     bool exhausted = false;
@@ -465,6 +466,8 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
         if (is_primary && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[py * fa.width + px] = prim_id;
         if (ready) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
+        long long sp1 = 0, sp2 = 0, sp3 = 0, sp4 = 0;
+        if (STATS) sp1 = (long long)__builtin_readcyclecounter();
         if (need_shade) {
             const Material mat = load_material(sc.materials, h.mat);
             const V3 V = -rd;
@@ -475,8 +478,10 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
                 float pdf = power_heuristics(light_pdf, mat_pdf);
                 col = col + g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
             }
+            if (STATS) sp2 = (long long)__builtin_readcyclecounter();
             // indirect bounce, raytracer.comp:913-921
             V3 bounce_dir = sample_mat(mat, V, h, seed);
+            if (STATS) sp3 = (long long)__builtin_readcyclecounter();
             float mat_pdf;
             V3 fr = eval_mat(mat, bounce_dir, V, h, mat_pdf);
             float cos_theta = g_abs(dot(h.normal, bounce_dir));
@@ -489,6 +494,16 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             bounce++;
             state = ST_TRACE_PATH;
             if (bounce > fa.max_bounces) end_sample = true;
+        }
+        if (STATS) {
+            sp4 = (long long)__builtin_readcyclecounter();
+            // sp2 / sp3 were taken inside a divergent branch: spread the value to every lane
+            for (int off = 32; off > 0; off >>= 1) {
+                long long o2 = __shfl_xor(sp2, off), o3 = __shfl_xor(sp3, off);
+                sp2 = o2 > sp2 ? o2 : sp2;
+                sp3 = o3 > sp3 ? o3 : sp3;
+            }
+            if (sp2 == 0) { sp2 = sp1; sp3 = sp1; }  // no lane of this wave shaded this round
         }
 
         if (end_sample) {
@@ -520,6 +535,11 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             cyc_gen += (unsigned long long)(stamp1 - stamp0);
             cyc_trace += (unsigned long long)(stamp2 - stamp1);
             cyc_shade += (unsigned long long)(stamp3 - stamp2);
+            cyc_part[0] += (unsigned long long)(sp1 - stamp2);
+            cyc_part[1] += (unsigned long long)(sp2 - sp1);
+            cyc_part[2] += (unsigned long long)(sp3 - sp2);
+            cyc_part[3] += (unsigned long long)(sp4 - sp3);
+            cyc_part[4] += (unsigned long long)(stamp3 - sp4);
         }
     }
 
@@ -544,6 +564,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, co
             atomicAdd((unsigned long long*)(fa.counters + 14), cyc_shade);
             atomicAdd((unsigned long long*)(fa.counters + 16), ni);
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
+            for (int k = 0; k < 5; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), cyc_part[k]);
         }
     }
 }
@@ -588,17 +609,32 @@ hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out,
     return hipGetLastError();
 }
 
-hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int grid_blocks,
-                         hipStream_t stream) {
-    dim3 grid((unsigned)grid_blocks), block(kBlock);
-    if (accel == 1) {
-        if (stats) hipLaunchKernelGGL((render_kernel<1, true>), grid, block, 0, stream, sc, fa);
-        else hipLaunchKernelGGL((render_kernel<1, false>), grid, block, 0, stream, sc, fa);
-    } else {
-        if (stats) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, 0, stream, sc, fa);
-        else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, 0, stream, sc, fa);
-    }
+namespace {
+template <typename K>
+hipError_t launch_persistent(K kernel, const DeviceScene& sc, const FrameArgs& fa, int cu_count, hipStream_t stream) {
+    // Persistent grid: as many workgroups as are resident at once (registers and the LDS
+    // traversal stacks decide), fewer when the image is small.
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    long long want = ((long long)fa.total_slots + kBlock - 1) / kBlock;
+    long long cap = (long long)cu_count * per_cu;
+    unsigned grid = (unsigned)(want < cap ? want : cap);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, sc, fa);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
+                         hipStream_t stream) {
+    if (accel == 1)
+        return stats ? launch_persistent(render_kernel<1, true>, sc, fa, cu_count, stream)
+                     : launch_persistent(render_kernel<1, false>, sc, fa, cu_count, stream);
+    return stats ? launch_persistent(render_kernel<0, true>, sc, fa, cu_count, stream)
+                 : launch_persistent(render_kernel<0, false>, sc, fa, cu_count, stream);
 }
 
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream) {

@@ -67,10 +67,6 @@ RT_DEV V3 align_to_world(V3 X, V3 N) {
 }
 
 // raytracer.comp:683-695
-RT_DEV V3 reflectance_v(float cos_theta, V3 F0) {
-    float p = g_pow(1.0f - cos_theta, 5.0f);
-    return g_clamp(F0 + (1.0f - F0) * p, 0.0f, 1.0f);
-}
 RT_DEV float fresnel_dielectric(float cos_theta_i, float eta) {
     float r0 = (1.0f - eta) / (1.0f + eta);
     float F0 = r0 * r0;
@@ -132,69 +128,82 @@ RT_DEV V3 sample_mat(const Material& mat, V3 V, const Hit& rec, uint32_t& seed) 
     return normalize(d);
 }
 
-// raytracer.comp:789-824
-RT_DEV V3 eval_brdf(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
-    V3 N = rec.normal;
-    float NdotL = dot(L, N);
-    float NdotV = dot(V, N);
-    V3 H = g_sign(NdotV) * normalize(L + V);
-    float VdotH = dot(V, H);
-    float NdotH = dot(N, H);
-
-    float ior_scale = g_mix(0.0f, 2.0f, mat.specular_tint_a);
-    float ri = rec.front_face ? (1.0f / (mat.ior * ior_scale)) : mat.ior * ior_scale;
-    float dielectric_F0 = (1.0f - ri) / (1.0f + ri);
-    V3 dielectric_F0_vec = v3(dielectric_F0 * dielectric_F0);
-    V3 F0 = g_mix(dielectric_F0_vec, mat.albedo, mat.metallic);
-    V3 f_diffuse = mat.albedo / kPi;
-
-    float alpha = mat.roughness * mat.roughness;
-    float D = ggx_distribution(alpha, N, H);
-    float G = G1_GGX(L, N, alpha) * G1_GGX(V, N, alpha);
-    V3 F = reflectance_v(VdotH, F0);
-
-    float ks = g_max(g_max(F.x, F.y), F.z);
-    float kd = (1.0f - ks) * (1.0f - mat.metallic);
-    float jacobian = 1.0f / g_max(0.00001f, 4.0f * NdotV * NdotL);
-    V3 f_specular = mat.specular_tint * D * G * F * jacobian;
-
-    float pdf_specular = g_clamp(D * NdotH * jacobian, 0.0f, 1.0f);
-    float pdf_diffuse = g_clamp(NdotL / kPi, 0.0f, 1.0f);
-    pdf = kd * pdf_diffuse + ks * pdf_specular;
-    return kd * f_diffuse + f_specular;
-}
-
-// raytracer.comp:826-855
-RT_DEV V3 eval_btdf(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
+// eval_mat (raytracer.comp:859-867) with eval_brdf (789-824) and eval_btdf (826-855) folded
+// into one body.  A lane takes exactly one of the two branches, but a wave usually holds
+// lanes of both kinds; the expensive pieces the branches have in common — the GGX
+// distribution, the two G1 terms (acos, tan, sqrt) and the Fresnel power — are therefore
+// evaluated ONCE for the whole wave on per-lane selected inputs.  Every lane still
+// performs, operation for operation, what its own branch of the shader performs.
+RT_DEV V3 eval_mat(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
     L = normalize(L);
-    V = normalize(V);
-    V3 N = normalize(rec.normal);
-    float eta_i = rec.front_face ? 1.0f : mat.ior;
-    float eta_o = rec.front_face ? mat.ior : 1.0f;
-    float eta = eta_i / eta_o;
-    V3 H = -normalize(L + eta * V);
-    float VoH = dot(V, H);
-    float LoH = dot(L, H);
-    float NoH = dot(N, H);
-    float VoN = dot(V, N);
-    float LoN = dot(L, N);
-    float alpha = mat.roughness * mat.roughness;
-    float D = ggx_distribution(alpha, N, H);
-    float G = G1_GGX(L, N, alpha) * G1_GGX(V, N, alpha);
-    float F = fresnel_dielectric(g_abs(VoH), eta);
+    const V3 Nn = normalize(rec.normal);
+    const bool reflect_side = dot(L, Nn) >= 0.0f;
+    const float alpha = mat.roughness * mat.roughness;
+
+    // per-lane inputs of the shared part
+    V3 Ls, Vs, Ns, Hs;
+    float cos_f;  // argument of the Fresnel power
+    // branch-private values carried to the epilogue
+    float NdotL = 0.0f, NdotV = 0.0f, NdotH = 0.0f;                       // BRDF
+    float VoH = 0.0f, LoH = 0.0f, NoH = 0.0f, VoN = 0.0f, LoN = 0.0f;     // BTDF
+    float eta = 1.0f, eta_i = 1.0f, eta_o = 1.0f;
+    if (reflect_side) {  // eval_brdf: N = rec.normal as stored, V as passed
+        const V3 N = rec.normal;
+        NdotL = dot(L, N);
+        NdotV = dot(V, N);
+        const V3 H = g_sign(NdotV) * normalize(L + V);
+        const float VdotH = dot(V, H);
+        NdotH = dot(N, H);
+        Ls = L; Vs = V; Ns = N; Hs = H;
+        cos_f = VdotH;
+    } else {  // eval_btdf: everything re-normalised
+        const V3 L2 = normalize(L);
+        const V3 V2 = normalize(V);
+        const V3 N2 = normalize(rec.normal);
+        eta_i = rec.front_face ? 1.0f : mat.ior;
+        eta_o = rec.front_face ? mat.ior : 1.0f;
+        eta = eta_i / eta_o;
+        const V3 H = -normalize(L2 + eta * V2);
+        VoH = dot(V2, H);
+        LoH = dot(L2, H);
+        NoH = dot(N2, H);
+        VoN = dot(V2, N2);
+        LoN = dot(L2, N2);
+        Ls = L2; Vs = V2; Ns = N2; Hs = H;
+        cos_f = g_abs(VoH);
+    }
+
+    // shared: D, G, (1 - cos)^5
+    const float D = ggx_distribution(alpha, Ns, Hs);
+    const float G = G1_GGX(Ls, Ns, alpha) * G1_GGX(Vs, Ns, alpha);
+    const float pw = g_pow(1.0f - cos_f, 5.0f);
+
+    if (reflect_side) {
+        float ior_scale = g_mix(0.0f, 2.0f, mat.specular_tint_a);
+        float ri = rec.front_face ? (1.0f / (mat.ior * ior_scale)) : mat.ior * ior_scale;
+        float dielectric_F0 = (1.0f - ri) / (1.0f + ri);
+        V3 dielectric_F0_vec = v3(dielectric_F0 * dielectric_F0);
+        V3 F0 = g_mix(dielectric_F0_vec, mat.albedo, mat.metallic);
+        V3 f_diffuse = mat.albedo / kPi;
+        V3 F = g_clamp(F0 + (1.0f - F0) * pw, 0.0f, 1.0f);  // reflectance(VdotH, F0), raytracer.comp:686-688
+        float ks = g_max(g_max(F.x, F.y), F.z);
+        float kd = (1.0f - ks) * (1.0f - mat.metallic);
+        float jacobian = 1.0f / g_max(0.00001f, 4.0f * NdotV * NdotL);
+        V3 f_specular = mat.specular_tint * D * G * F * jacobian;
+        float pdf_specular = g_clamp(D * NdotH * jacobian, 0.0f, 1.0f);
+        float pdf_diffuse = g_clamp(NdotL / kPi, 0.0f, 1.0f);
+        pdf = kd * pdf_diffuse + ks * pdf_specular;
+        return kd * f_diffuse + f_specular;
+    }
+    // fresnel_dielectric(abs(VoH), eta), raytracer.comp:691-695
+    float r0 = (1.0f - eta) / (1.0f + eta);
+    float F0d = r0 * r0;
+    float F = F0d + (1.0f - F0d) * pw;
     float x = g_abs(VoH) / g_max(0.00001f, g_abs(VoN) * g_abs(LoN));
     float denom = eta_i * VoH + eta_o * LoH;
     float jacobian = (eta_o * eta_o * g_abs(LoH)) / g_max(0.00001f, denom * denom);
     pdf = D * g_abs(NoH) * jacobian;
     return mat.subsurface * x * jacobian * D * G * (1.0f - F);
-}
-
-// raytracer.comp:859-867
-RT_DEV V3 eval_mat(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) {
-    L = normalize(L);
-    V3 N = normalize(rec.normal);
-    if (dot(L, N) >= 0.0f) return eval_brdf(mat, L, V, rec, pdf);
-    return eval_btdf(mat, L, V, rec, pdf);
 }
 
 }  // namespace rtd

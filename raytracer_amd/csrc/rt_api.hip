@@ -350,13 +350,8 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 88, c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     if (fa.total_slots > 0) {
-        // Persistent grid: at most four 256-thread workgroups per CU (the LDS traversal stacks
-        // of four workgroups fill 128 of the CU's 160 KiB), fewer when the image is small.
-        long long want = ((long long)fa.total_slots + rtd::kBlock - 1) / rtd::kBlock;
-        long long cap = (long long)c->cu_count * 4;
-        int grid = (int)(want < cap ? want : cap);
         bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
-        RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, grid, c->stream));
+        RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, c->cu_count, c->stream));
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
     c->timed = true;
@@ -420,6 +415,7 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memcpy(&out->cycles_shade, &h[14], 8);
     memcpy(&out->lane_iterations, &h[16], 8);
     memcpy(&out->wave_iterations, &h[18], 8);
+    memcpy(out->cycles_shade_parts, &h[20], 40);
     if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;

@@ -17,4 +17,6 @@ for flags in (0, 0, capi.RT_FLAG_TRAVERSAL_STATS):
 tot = st.cycles_raygen + st.cycles_search + st.cycles_shade
 print(f"nodes/ray={st.nodes_visited/st.rays:.2f} tests/ray={st.prims_tested/st.rays:.2f}")
 print(f"wave cycles: raygen {st.cycles_raygen/tot:.3f} search {st.cycles_search/tot:.3f} shade {st.cycles_shade/tot:.3f}")
+sp = list(st.cycles_shade_parts)
+print("continuation split (hit+light pick, direct BSDF, sampling, indirect BSDF, end): " + " ".join(f"{x/max(1,sum(sp)):.3f}" for x in sp))
 print(f"traversal lane occupancy: {st.lane_iterations/(64*max(1,st.wave_iterations)):.3f} (lane iters {st.lane_iterations}, wave iters {st.wave_iterations})")
