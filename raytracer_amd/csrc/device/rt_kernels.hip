@@ -212,7 +212,7 @@ RT_DEV uint32_t resolve_pixel(float4 a, int c) {
 enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2 };
 
 template <int ACCEL, bool STATS>
-__global__ void __launch_bounds__(kBlock) render_kernel(const DeviceScene sc, const FrameArgs fa) {
+__global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc, const FrameArgs fa) {
     __shared__ uint32_t s_stack[(ACCEL == 1) ? (kStackDepth * kBlock) : 1];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
