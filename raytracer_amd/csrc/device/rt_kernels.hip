@@ -110,7 +110,9 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __res
     float dx = (g_abs(rd.x) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.x) : rd.x;
     float dy = (g_abs(rd.y) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.y) : rd.y;
     float dz = (g_abs(rd.z) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.z) : rd.z;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // The box test only has to be conservative, so the hardware's approximate reciprocal
+    // (1 ulp) is enough here; the exact arithmetic is kept for the primitive tests.
+    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     const float ox = -(ro.x * ix), oy = -(ro.y * iy), oz = -(ro.z * iz);
     const float4* __restrict__ nodes = sc.nodes;
 
@@ -141,8 +143,8 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __res
                 float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), tv.best_t));
                 // an unused child slot (child index -1, inverted box) must never be entered: the slab
                 // arithmetic on its infinities would report a hit
-                const bool hit0 = (tmin0 <= tmax0 * 1.0000005f) && (__float_as_int(q3.x) >= 0);
-                const bool hit1 = (tmin1 <= tmax1 * 1.0000005f) && (__float_as_int(q3.y) >= 0);
+                const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.x) >= 0);
+                const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.y) >= 0);
                 int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
                 int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
                 if (hit0 && hit1) {
@@ -471,7 +473,10 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
         if (need_shade) {
             const Material mat = load_material(sc.materials, h.mat);
             const V3 V = -rd;
-            if (have_direct) {  // direct_light, raytracer.comp:870-881
+            // direct_light, raytracer.comp:870-881.  With no emission arriving (Le == 0: occluded,
+            // facing away, no lights) the term is clamp(0 * fr * cos / pdf) = +0 whatever fr is
+            // (a NaN clamps to 0 too), and the attenuation at bounce 0 is 1: nothing to add.
+            if (have_direct && (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f)) {
                 float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
                 float mat_pdf;
                 V3 fr = eval_mat(mat, Ldir, V, h, mat_pdf);

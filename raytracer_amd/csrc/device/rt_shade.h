@@ -105,16 +105,16 @@ RT_DEV V3 sample_ggx(float roughness, V3 V, V3 N, uint32_t& seed) {
 }
 
 // raytracer.comp:751-785
+// Both branches (sample_r, sample_t) start with the same sample_ggx call right after the
+// branch draw, so the half vector is sampled once, for all lanes, before the branch.
 RT_DEV V3 sample_mat(const Material& mat, V3 V, const Hit& rec, uint32_t& seed) {
-    if (mat.trs_weight < rng_random(seed)) {
-        V3 H = sample_ggx(mat.roughness, V, rec.normal, seed);
-        return normalize(g_reflect(-V, H));
-    }
+    const bool reflect_only = mat.trs_weight < rng_random(seed);
+    const V3 H = sample_ggx(mat.roughness, V, rec.normal, seed);
+    if (reflect_only) return normalize(g_reflect(-V, H));  // sample_r
     float eta_i = rec.front_face ? 1.0f : mat.ior;
     float eta_o = rec.front_face ? mat.ior : 1.0f;
     float eta = eta_i / eta_o;
     // sample_t
-    V3 H = sample_ggx(mat.roughness, V, rec.normal, seed);
     float cos_theta = g_min(1.0f, dot(V, H));
     float sin_theta = g_sqrt(1.0f - cos_theta * cos_theta);
     bool cannot_refract = eta * sin_theta > 1.0f;
