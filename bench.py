@@ -25,17 +25,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from raytracer_amd import capi, parallel  # noqa: E402
-from raytracer_amd.renderer import Context, Scene, default_camera, look_camera, make_params  # noqa: E402
+from raytracer_amd.renderer import Context, Scene, default_camera, make_params  # noqa: E402
+from raytracer_amd.workloads import WORKLOADS, workload_camera  # noqa: E402
 
-WORKLOADS = {
-    # name: (scene preset, width, height, spp, max_bounces, description)
-    "c3": (capi.RT_SCENE_CORNELL_TEAPOT, 1920, 1080, 16, 4,
-           "Cornell box + teapot.glb (6360 primitives), 1920x1080, 16 spp, 4 bounces"),
-    "c2": (capi.RT_SCENE_CORNELL_STAR, 1920, 1080, 4, 20,
-           "reference default scene (Cornell box + star.glb, 100 primitives), 1920x1080, 4 spp, 20 bounces"),
-    "c5": (capi.RT_SCENE_TEAPOT_GRID, 1920, 1080, 8, 20,
-           "13x13 teapot grid (1 068 084 primitives), 1920x1080, 8 spp, 20 bounces"),
-}
 STRIP_ROWS = 9  # 1080 / 9 = 120 strips: divisible by 1, 2, 4 and 8 ranks
 
 # MI355X vector FP32 peak (spec): 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
@@ -100,10 +92,7 @@ def main() -> None:
     bgra = torch.zeros((H, W), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     ctx.bind_framebuffer(W, H, acc.data_ptr(), cnt.data_ptr(), bgra.data_ptr())
-    if args.workload == "c5":
-        cam = look_camera((3.0, 7.0, -9.0), (0.0, -0.38, 1.0), (0.0, 1.0, 0.0), 50.0, W, H)
-    else:
-        cam = default_camera(W, H)
+    cam = workload_camera(args.workload, W, H)
     strip = (STRIP_ROWS, world, rank) if collective else (0, 1, 0)
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
