@@ -28,6 +28,7 @@ from raytracer_amd import capi, parallel  # noqa: E402
 from raytracer_amd.renderer import Context, Scene, default_camera, make_params  # noqa: E402
 from raytracer_amd.workloads import WORKLOADS, workload_camera  # noqa: E402
 
+FRAMES_PER_BATCH = 16  # sample sharding: frames per progressive batch (c4: 16 x 4 spp = 64 spp)
 STRIP_ROWS = 9  # 1080 / 9 = 120 strips: divisible by 1, 2, 4 and 8 ranks
 
 # MI355X vector FP32 peak (spec): 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
@@ -61,6 +62,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--accel", default="bvh", choices=["bvh", "flat"])
+    ap.add_argument("--partition", default=None, choices=["strips", "samples"],
+                    help="how N GPUs share the work: row strips of every frame (default) or whole frames "
+                         "(sample sharding, default for c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
@@ -93,12 +97,30 @@ def main() -> None:
     torch.cuda.synchronize()
     ctx.bind_framebuffer(W, H, acc.data_ptr(), cnt.data_ptr(), bgra.data_ptr())
     cam = workload_camera(args.workload, W, H)
-    strip = (STRIP_ROWS, world, rank) if collective else (0, 1, 0)
+    partition = args.partition or ("samples" if args.workload == "c4" else "strips")
+    frames_per_step = FRAMES_PER_BATCH if partition == "samples" else 1
+    strip = (STRIP_ROWS, world, rank) if (collective and partition == "strips") else (0, 1, 0)
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     main_stream = torch.cuda.current_stream(dev)
 
     def step(frame: int, ev=None) -> None:
+        if partition == "samples":
+            # one step = one progressive batch: FRAMES_PER_BATCH frames of `spp` samples, frames dealt
+            # round-robin to the ranks, each rank accumulating privately (reset on its first frame)
+            own = parallel.frames_of(FRAMES_PER_BATCH, world, rank)
+            if ev is not None:
+                ev[0].record(rt_stream)
+            for i, f in enumerate(own):
+                ctx.render_frame(cam, scene.push_constants(0.0, frame * FRAMES_PER_BATCH + f, i == 0), params)
+            if ev is not None:
+                ev[1].record(rt_stream)
+            if collective:
+                main_stream.wait_stream(rt_stream)
+                parallel.reduce_samples(acc, cnt)
+                rt_stream.wait_stream(main_stream)
+            ctx.resolve()
+            return
         pc = scene.push_constants(0.0, frame, frame == 0)
         if ev is not None:
             ev[0].record(rt_stream)
@@ -128,7 +150,8 @@ def main() -> None:
     fence()
     t1 = time.perf_counter()
     rays = ctx.stats().total_rays - rays0
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    own_frames = len(parallel.frames_of(FRAMES_PER_BATCH, world, rank)) if partition == "samples" else 1
+    kernel_ms = [a.elapsed_time(b) / max(1, own_frames) for a, b in events]  # per launch
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
@@ -152,8 +175,12 @@ def main() -> None:
     if rank == 0:
         v = scene.view()
         n_prims = st.total_prims
-        pixels_per_launch = W * H / world
-        rays_per_launch = job_rays / args.steps / world
+        if partition == "samples":  # a launch is a whole frame on one rank
+            pixels_per_launch = W * H
+            rays_per_launch = job_rays / args.steps / FRAMES_PER_BATCH
+        else:
+            pixels_per_launch = W * H / world
+            rays_per_launch = job_rays / args.steps / world
         if accel == capi.RT_ACCEL_BVH:
             # per ray: 2 box tests (24 flop each) per visited node, 51 flop per triangle test;
             # 64 B per visited node, 48 B per tested primitive record; + 48 B framebuffer per pixel
@@ -165,6 +192,16 @@ def main() -> None:
         launch_flops = flops_per_ray * rays_per_launch
         launch_bytes = bytes_per_ray * rays_per_launch + 48.0 * pixels_per_launch
         achieved_tflops = launch_flops / (avg_kernel_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_passes.sh) of
+        # this workload on one GPU; bench.py cannot run the profiler on itself.
+        traffic, traffic_note = None, None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if rec and world == 1 and args.accel == "bvh":
+                traffic = (rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024.0
+                traffic_note = rec["note"]
+        except (OSError, ValueError, KeyError):
+            pass
         result = {
             "metric": "Mrays/s",
             "value": job_rays / elapsed_s / 1e6,
@@ -173,14 +210,18 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
+            "ms_per_frame": elapsed_s / args.steps / frames_per_step * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "search": args.accel,
-                       "partition": f"row strips of {STRIP_ROWS} rows, all-gather" if collective else "single GPU",
-                       "rays_per_frame": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
+                       "partition": ("single GPU" if not collective else
+                                     f"row strips of {STRIP_ROWS} rows, all-gather" if partition == "strips" else
+                                     f"frames of a {FRAMES_PER_BATCH}-frame batch dealt to ranks, all-reduce of accumulators"),
+                       "frames_per_step": frames_per_step,
+                       "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
             "roofline": {
                 "bound": "valu",
                 "kernel": "render_kernel",
@@ -188,7 +229,8 @@ def main() -> None:
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "avg_kernel_ms": avg_kernel_ms,
                 "flops_per_ray": flops_per_ray,
                 "bytes_per_ray": bytes_per_ray,
