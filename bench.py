@@ -38,11 +38,11 @@ PEAK_HBM_GBPS = 8000.0
 
 def cpu_baseline(scene: Scene, max_bounces: int) -> dict:
     """The CPU oracle (flat search = the reference's algorithm) on a bounded sample of the
-    same scene and camera: 640x360 pixels, 1 spp (about 30 s of single-core work)."""
+    same scene and camera: 1280x720 pixels, 2 spp (about 15 s on the GPU box's 16-core share)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    w, h, spp = 640, 360, 1
+    w, h, spp = 1280, 720, 2
     threads = max(1, min(16, os.cpu_count() or 1))
     cam = default_camera(w, h)
     osc = ob.OracleScene(scene.arrays())

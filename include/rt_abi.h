@@ -133,7 +133,13 @@ typedef struct RtParams {
 enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id per pixel       */
        RT_FLAG_PATH_HASH   = 2u,   /* record a hash of every nearest-hit id along the paths    */
        RT_FLAG_COUNT_RAYS  = 4u,   /* accepted, no effect: rays are always counted             */
-       RT_FLAG_TRAVERSAL_STATS = 8u /* count BVH nodes visited / primitives tested             */ };
+       RT_FLAG_TRAVERSAL_STATS = 8u, /* count BVH nodes visited / primitives tested            */
+       RT_FLAG_WAVEFRONT   = 16u,  /* staged pipeline: one search launch + one shading launch
+                                      per ray generation instead of the single persistent kernel;
+                                      same results                                              */
+       RT_FLAG_POOLED      = 32u   /* pooled pipeline: one persistent launch whose workgroups keep
+                                      four paths per lane and regroup them by kind of work through
+                                      queues in LDS; same results                                */ };
 
 typedef struct RtStats {
     uint64_t rays;          /* nearest-hit searches in the last frame (always counted)         */

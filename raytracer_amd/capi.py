@@ -32,6 +32,8 @@ RT_FLAG_PRIMARY_IDS = 1
 RT_FLAG_PATH_HASH = 2
 RT_FLAG_COUNT_RAYS = 4
 RT_FLAG_TRAVERSAL_STATS = 8
+RT_FLAG_WAVEFRONT = 16
+RT_FLAG_POOLED = 32
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1

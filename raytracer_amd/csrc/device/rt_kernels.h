@@ -39,6 +39,8 @@ struct FrameArgs {
     uint32_t total_slots;                           // tiles_x * ceil(owned_rows / 8) * 64
     uint32_t flags;
     int32_t exit_quota_pct;  // the search loop returns once this share of the wave's busy lanes has finished
+    int32_t accel;           // RT_ACCEL_*: which record array the search results index
+    int32_t stack_depth;     // entries per traversal stack (staged pipeline: sized to the scene's BVH)
     // outputs
     float4* accum;
     int32_t* counts;
@@ -55,8 +57,43 @@ struct FrameArgs {
 
 enum { kBlock = 256, kStackDepth = 32 };
 
+// Path state of the staged pipeline: one slot per pixel in flight, structure of arrays in
+// device memory.  `stage` says what a slot waits for between launches.
+enum : uint32_t {
+    WF_IDLE = 0,          // no path (pixel finished, or slot outside the image)
+    WF_PATH_FIRST = 1,    // path ray at bounce 0 awaits the nearest-hit search
+    WF_LIGHT_SEARCH = 2,  // light-visibility ray awaits the search
+    WF_LIGHT_AMBIENT = 3, // light picked, no search needed: arrival known (AMBIENT)
+    WF_LIGHT_NONE = 4,    // light picked, no search needed: nothing arrives (DIRECTIONAL facing away)
+    WF_LIGHT_UNDEF = 5,   // light picked, no search needed: the shader's undefined light types
+    WF_PATH_NEXT = 6      // path ray at bounce > 0 awaits the search
+};
+struct PathPool {
+    uint32_t* stage;
+    uint4* ctl;     // RNG state, pixel index (y * width + x), sample, bounce
+    float4* ray_o;  // origin of the ray handed to the search; w = distance to the sampled light point
+    float4* ray_d;  // its direction; w (bits) = index of the picked light
+    uint2* hit;     // search result: t (bits), primitive record index (-1: none)
+    float4* att;    // path attenuation; w (bits) = hash of the nearest-hit ids so far
+    float4* col;    // radiance of the current sample
+    float4* pix;    // sum of this pixel's finished samples
+    float4* hp;     // shading point kept across a light query; w (bits) = material | front_face << 31
+    float4* hn;     // shading normal kept across a light query
+    float4* vdir;   // direction of the path ray that reached the shading point
+    uint32_t* active;  // [iterations + 1] slots still in flight at the start of each iteration
+    uint32_t n_slots;
+};
+
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
                          hipStream_t stream);
+// The staged pipeline: generate, then `iterations` x (search launch, shading launch).
+hipError_t launch_wavefront(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, int iterations,
+                            int refill_min, int cu_count, hipStream_t stream);
+// The pooled pipeline: one persistent launch, path slots regrouped through LDS queues.
+int pool_slots_per_block();
+hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, unsigned* grid);
+hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
+                       int refill_min, int burst, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);
 

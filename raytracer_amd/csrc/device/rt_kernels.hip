@@ -9,88 +9,11 @@
 // wave-local reserve refilled by one atomic per 64 pixels (ballot + popcount ranking), so
 // terminated paths do not leave lanes idle.  Each pixel is still computed by exactly one
 // lane, sequentially, with its own RNG state: results do not depend on scheduling.
-#include "rt_kernels.h"
-#include "rt_shade.h"
+#include "rt_trace.h"
 
 namespace rtd {
 
 namespace {
-
-RT_DEV bool surrounds(float x) { return 0.005f < x && kInf > x; }  // Interval(0.005, PINF), raytracer.comp:310-312
-
-// One primitive against one ray; keeps the winner under the reference's tie rules
-// (lower t; equal t: lower prio).  Triangle: raytracer.comp:366-406 / 412-449 with the two
-// edges precomputed; sphere: raytracer.comp:334-361.
-RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
-                             int& best_idx) {
-    const float4 A = recs[3 * idx + 0];
-    const float4 B = recs[3 * idx + 1];
-    const float4 C = recs[3 * idx + 2];
-    const int prio = __float_as_int(B.w);
-    float t;
-    if (__float_as_int(C.w) < 0) {  // sphere: A.xyz centre, B.x radius
-        V3 oc = v3(A.x, A.y, A.z) - ro;
-        float a = dot(rd, rd);
-        float h = dot(rd, oc);
-        float c = dot(oc, oc) - B.x * B.x;
-        float disc = h * h - a * c;
-        if (disc < 0.0f) return;
-        float srtd = g_sqrt(disc);
-        t = (h - srtd) / a;
-        if (!surrounds(t)) {
-            t = (h + srtd) / a;
-            if (!surrounds(t)) return;
-        }
-    } else {  // triangle: A.xyz = v0, B.xyz = v1 - v0, C.xyz = v2 - v0
-        V3 e1 = v3(B.x, B.y, B.z);
-        V3 e2 = v3(C.x, C.y, C.z);
-        V3 h = cross(rd, e2);
-        float a = dot(e1, h);
-        if (g_abs(a) < 1e-6f) return;
-        float f = 1.0f / a;
-        V3 s = ro - v3(A.x, A.y, A.z);
-        float u = f * dot(s, h);
-        if (u < 0.0f || u > 1.0f) return;
-        V3 q = cross(s, e1);
-        float v = f * dot(rd, q);
-        if (v < 0.0f || u + v > 1.0f) return;
-        t = f * dot(e2, q);
-        if (!surrounds(t)) return;
-    }
-    if (t < best_t || (t == best_t && prio < best_prio)) {
-        best_t = t;
-        best_prio = prio;
-        best_idx = idx;
-    }
-}
-
-// The reference's search: every primitive, in the order of its three loops.
-RT_DEV void trace_flat(const DeviceScene& sc, V3 ro, V3 rd, float& best_t, int& best_idx) {
-    int best_prio = 0x7fffffff;
-    for (int i = 0; i < sc.n_prims; ++i) intersect_record(sc.prims_flat, i, ro, rd, best_t, best_prio, best_idx);
-}
-
-// Traversal cursor of one lane: >= 0 an internal node index (below kTravDone); < 0 a leaf,
-// bit 31 | (count-1) << 28 | first record; kTravDone when the search has finished.
-static constexpr int kTravDone = 0x7fffffff;
-RT_DEV int encode_child(int child, int count) { return count > 0 ? (int)(0x80000000u | ((uint32_t)(count - 1) << 28) | (uint32_t)child) : child; }
-
-struct Trav {
-    int cur;        // cursor (see above)
-    int sp;         // entries on this lane's LDS stack
-    float best_t;   // winner so far
-    int best_prio;
-    int best_idx;   // record index of the winner, -1 = none
-};
-
-RT_DEV void trav_pop(Trav& tv, const uint32_t* __restrict__ stack) {
-    if (tv.sp == 0) {
-        tv.cur = kTravDone;
-    } else {
-        tv.sp--;
-        tv.cur = (int)stack[tv.sp * kBlock];
-    }
-}
 
 // Resumable nearest-hit search over the binary BVH (both child boxes in the parent; per-lane
 // stack in LDS: column `tid` of a [depth][block] array, lane-private, bank = tid mod 32 at
@@ -171,44 +94,6 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __res
             }
         }
     }
-}
-
-// Hit record of the winning primitive (raytracer.comp:354-358, 398-403, 454-461).
-RT_DEV void make_hit(const DeviceScene& sc, const float4* __restrict__ recs, int idx, float t, V3 ro, V3 rd, Hit& h,
-                     int& prim_id) {
-    const float4 A = recs[3 * idx + 0];
-    const float4 B = recs[3 * idx + 1];
-    const float4 C = recs[3 * idx + 2];
-    prim_id = __float_as_int(A.w);
-    const int matbits = __float_as_int(C.w);
-    h.t = t;
-    h.p = ro + t * rd;
-    V3 outward;
-    if (matbits < 0) {
-        h.mat = matbits & 0x7fffffff;
-        outward = (h.p - v3(A.x, A.y, A.z)) / B.x;
-    } else {
-        h.mat = matbits;
-        if (prim_id < sc.n_spheres + sc.n_triangles) {
-            const float4 n = sc.triangles[4 * (prim_id - sc.n_spheres) + 3];  // stored Triangle.normal
-            outward = v3(n.x, n.y, n.z);
-        } else {
-            outward = normalize(cross(v3(B.x, B.y, B.z), v3(C.x, C.y, C.z)));
-        }
-    }
-    h.front_face = dot(rd, outward) < 0.0f;  // set_face_normal, raytracer.comp:322-329
-    h.normal = h.front_face ? outward : -outward;
-}
-
-RT_DEV uint32_t pack_unorm8(float x) {
-    float c = g_clamp(x, 0.0f, 1.0f);  // NaN -> 0
-    return (uint32_t)__builtin_rintf(c * 255.0f);
-}
-
-// raytracer.comp:984-995: accumulate one frame's colour, write acc/count as B,G,R,A bytes
-RT_DEV uint32_t resolve_pixel(float4 a, int c) {
-    float d = (float)((c > 1) ? c : 1);
-    return pack_unorm8(a.z / d) | (pack_unorm8(a.y / d) << 8) | (pack_unorm8(a.x / d) << 16) | (pack_unorm8(a.w / d) << 24);
 }
 
 enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2 };

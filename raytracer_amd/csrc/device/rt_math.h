@@ -76,6 +76,32 @@ RT_DEV float g_cos(float xx) {
     return neg ? -r : r;
 }
 
+// sin and cos of one angle: the two functions above share the octant reduction and both
+// polynomials; evaluated together they cost little more than one of them.  Bit for bit
+// the same values as g_sin(xx) and g_cos(xx).
+RT_DEV void g_sincos(float xx, float& s, float& c) {
+    float x = g_abs(xx);
+    if (!(x <= kTrigMax)) {
+        s = xx - xx;
+        c = s;
+        return;
+    }
+    int j = (int)(kFOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    bool sneg = xx < 0.0f, cneg = false;
+    if (j > 3) { j -= 4; sneg = !sneg; cneg = !cneg; }
+    if (j > 1) cneg = !cneg;
+    x = ((x - y * kDP1) - y * kDP2) - y * kDP3;
+    const float z = x * x;
+    const float ps = poly_sin(x, z), pc = poly_cos(z);
+    const bool swap = (j == 1 || j == 2);
+    const float rs = swap ? pc : ps, rc = swap ? ps : pc;
+    s = sneg ? -rs : rs;
+    c = cneg ? -rc : rc;
+}
+
 RT_DEV float g_tan(float xx) {
     float x = g_abs(xx);
     if (!(x <= kTrigMax)) return xx - xx;
@@ -96,21 +122,23 @@ RT_DEV float g_tan(float xx) {
     return neg ? -r : r;
 }
 
-// asin on [-1,1] (outside: NaN)
+// asin polynomial on [0, 0.5]: x + x * z * P(z), z = x * x
+RT_DEV float poly_asin(float x, float z) {
+    return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z +
+            1.6666752422e-1f) * z * x + x;
+}
+
+// asin on [-1,1] (outside: NaN): |x| <= 0.5: the polynomial; above: pi/2 - 2 asin(sqrt((1 - |x|) / 2)).
+// Both ranges run the one polynomial on per-lane selected arguments (z is (1 - |x|) / 2 itself
+// in the upper range, not the square of its root).
 RT_DEV float g_asin(float xx) {
     float a = g_abs(xx);
     if (!(a <= 1.0f)) return u2f(0x7fc00000u);
-    float x, z;
-    bool flag = a > 0.5f;
-    if (flag) {
-        z = 0.5f * (1.0f - a);
-        x = g_sqrt(z);
-    } else {
-        x = a;
-        z = x * x;
-    }
-    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z +
-               1.6666752422e-1f) * z * x + x;
+    const bool flag = a > 0.5f;
+    const float zf = 0.5f * (1.0f - a);
+    const float x = flag ? g_sqrt(zf) : a;
+    const float z = flag ? zf : a * a;
+    float r = poly_asin(x, z);
     if (flag) {
         r = r + r;
         r = 1.5707963267948966192f - r;
@@ -118,11 +146,18 @@ RT_DEV float g_asin(float xx) {
     return (xx < 0.0f) ? -r : r;
 }
 
+// acos(x) = pi - 2 asin(sqrt((1 + x) / 2)) below -0.5, 2 asin(sqrt((1 - x) / 2)) above 0.5,
+// pi/2 - asin(x) between.  The inner asin arguments never exceed 0.5, so every range is the
+// one polynomial on a per-lane selected argument w (z = w * w in all three ranges).
 RT_DEV float g_acos(float x) {
-    if (!(g_abs(x) <= 1.0f)) return u2f(0x7fc00000u);
-    if (x < -0.5f) return kPi - 2.0f * g_asin(g_sqrt(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * g_asin(g_sqrt(0.5f * (1.0f - x)));
-    return 1.5707963267948966192f - g_asin(x);
+    const float a = g_abs(x);
+    if (!(a <= 1.0f)) return u2f(0x7fc00000u);
+    const bool tail = a > 0.5f;
+    // 0.5 * (1 + x) for x < -0.5 and 0.5 * (1 - x) for x > 0.5 are the same operation on |x|
+    const float w = tail ? g_sqrt(0.5f * (1.0f - a)) : a;
+    const float r = poly_asin(w, w * w);
+    if (tail) return (x < 0.0f) ? (kPi - 2.0f * r) : (2.0f * r);
+    return 1.5707963267948966192f - ((x < 0.0f) ? -r : r);
 }
 
 // ---- pow(x, y) = exp2(y * log2(x)), the GLSL definition ---------------------------------

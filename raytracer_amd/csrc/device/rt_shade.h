@@ -37,8 +37,10 @@ RT_DEV Material load_material(const float4* __restrict__ mats, int idx) {
 RT_DEV V3 random_unit_vec(uint32_t& seed) {
     float phi = (2.0f * kPi) * rng_random(seed);
     float theta = g_acos(2.0f * rng_random(seed) - 1.0f);
-    float sin_theta = g_sin(theta);
-    return v3(sin_theta * g_cos(phi), sin_theta * g_sin(phi), g_cos(theta));
+    float sin_theta, cos_theta, sin_phi, cos_phi;
+    g_sincos(theta, sin_theta, cos_theta);
+    g_sincos(phi, sin_phi, cos_phi);
+    return v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
 }
 RT_DEV V3 random_vec_on_hemisphere(V3 normal, uint32_t& seed) {
     V3 r = random_unit_vec(seed);
@@ -54,8 +56,10 @@ RT_DEV float power_heuristics(float a, float b) {
 
 // raytracer.comp:260-267
 RT_DEV V3 sphere_to_cartesian(float theta, float phi) {
-    float sin_t = g_sin(theta);
-    return v3(sin_t * g_cos(phi), sin_t * g_sin(phi), g_cos(theta));
+    float sin_t, cos_t, sin_p, cos_p;
+    g_sincos(theta, sin_t, cos_t);
+    g_sincos(phi, sin_p, cos_p);
+    return v3(sin_t * cos_p, sin_t * sin_p, cos_t);
 }
 
 // raytracer.comp:279-292

@@ -1,0 +1,320 @@
+// rt_trace.h — nearest-hit search building blocks shared by the single-kernel pipeline
+// (rt_kernels.hip) and the staged pipeline (rt_wavefront.hip): one primitive test with the
+// reference's tie rules, the resumable BVH step, the hit record and the rgba8 store.
+#pragma once
+#include "rt_kernels.h"
+#include "rt_shade.h"
+
+namespace rtd {
+
+RT_DEV bool surrounds(float x) { return 0.005f < x && kInf > x; }  // Interval(0.005, PINF), raytracer.comp:310-312
+
+// One primitive against one ray; keeps the winner under the reference's tie rules
+// (lower t; equal t: lower prio).  Triangle: raytracer.comp:366-406 / 412-449 with the two
+// edges precomputed; sphere: raytracer.comp:334-361.
+RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
+                             int& best_idx) {
+    const float4 A = recs[3 * idx + 0];
+    const float4 B = recs[3 * idx + 1];
+    const float4 C = recs[3 * idx + 2];
+    const int prio = __float_as_int(B.w);
+    float t;
+    if (__float_as_int(C.w) < 0) {  // sphere: A.xyz centre, B.x radius
+        V3 oc = v3(A.x, A.y, A.z) - ro;
+        float a = dot(rd, rd);
+        float h = dot(rd, oc);
+        float c = dot(oc, oc) - B.x * B.x;
+        float disc = h * h - a * c;
+        if (disc < 0.0f) return;
+        float srtd = g_sqrt(disc);
+        t = (h - srtd) / a;
+        if (!surrounds(t)) {
+            t = (h + srtd) / a;
+            if (!surrounds(t)) return;
+        }
+    } else {  // triangle: A.xyz = v0, B.xyz = v1 - v0, C.xyz = v2 - v0
+        V3 e1 = v3(B.x, B.y, B.z);
+        V3 e2 = v3(C.x, C.y, C.z);
+        V3 h = cross(rd, e2);
+        float a = dot(e1, h);
+        if (g_abs(a) < 1e-6f) return;
+        float f = 1.0f / a;
+        V3 s = ro - v3(A.x, A.y, A.z);
+        float u = f * dot(s, h);
+        if (u < 0.0f || u > 1.0f) return;
+        V3 q = cross(s, e1);
+        float v = f * dot(rd, q);
+        if (v < 0.0f || u + v > 1.0f) return;
+        t = f * dot(e2, q);
+        if (!surrounds(t)) return;
+    }
+    if (t < best_t || (t == best_t && prio < best_prio)) {
+        best_t = t;
+        best_prio = prio;
+        best_idx = idx;
+    }
+}
+
+// The reference's search: every primitive, in the order of its three loops.
+RT_DEV void trace_flat(const DeviceScene& sc, V3 ro, V3 rd, float& best_t, int& best_idx) {
+    int best_prio = 0x7fffffff;
+    for (int i = 0; i < sc.n_prims; ++i) intersect_record(sc.prims_flat, i, ro, rd, best_t, best_prio, best_idx);
+}
+
+// Traversal cursor of one lane: >= 0 an internal node index (below kTravDone); < 0 a leaf,
+// bit 31 | (count-1) << 28 | first record; kTravDone when the search has finished.
+static constexpr int kTravDone = 0x7fffffff;
+RT_DEV int encode_child(int child, int count) { return count > 0 ? (int)(0x80000000u | ((uint32_t)(count - 1) << 28) | (uint32_t)child) : child; }
+
+struct Trav {
+    int cur;        // cursor (see above)
+    int sp;         // entries on this lane's LDS stack
+    float best_t;   // winner so far
+    int best_prio;
+    int best_idx;   // record index of the winner, -1 = none
+};
+
+RT_DEV void trav_reset(Trav& tv, int cur) {
+    tv.cur = cur;
+    tv.sp = 0;
+    tv.best_t = kInf;
+    tv.best_prio = 0x7fffffff;
+    tv.best_idx = -1;
+}
+
+RT_DEV void trav_pop(Trav& tv, const uint32_t* __restrict__ stack) {
+    if (tv.sp == 0) {
+        tv.cur = kTravDone;
+    } else {
+        tv.sp--;
+        tv.cur = (int)stack[tv.sp * kBlock];
+    }
+}
+
+// Constants of the slab test for one ray: t = box * inv + off per axis.  The arithmetic
+// runs on a direction with no zero component; the boxes are padded on the host by far more
+// than the half-ulp origin perturbation the fused form implies.  The box test only has to
+// be conservative, so the hardware's approximate reciprocal (1 ulp) is enough here; the
+// exact arithmetic is kept for the primitive tests.
+struct Slab {
+    float ix, iy, iz, ox, oy, oz;
+};
+RT_DEV Slab make_slab(V3 ro, V3 rd) {
+    float dx = (g_abs(rd.x) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.x) : rd.x;
+    float dy = (g_abs(rd.y) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.y) : rd.y;
+    float dz = (g_abs(rd.z) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.z) : rd.z;
+    Slab s;
+    s.ix = __builtin_amdgcn_rcpf(dx);
+    s.iy = __builtin_amdgcn_rcpf(dy);
+    s.iz = __builtin_amdgcn_rcpf(dz);
+    s.ox = -(ro.x * s.ix);
+    s.oy = -(ro.y * s.iy);
+    s.oz = -(ro.z * s.iz);
+    return s;
+}
+
+// Visit the internal node under the cursor: slab-test both children, descend into the
+// nearer hit child, push the other (per-lane stack: column of a [depth][block] LDS array,
+// bank = tid mod 32 at every depth, so conflict-free).
+RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, uint32_t* __restrict__ stack, Trav& tv) {
+    const float4 q0 = nodes[4 * tv.cur + 0];
+    const float4 q1 = nodes[4 * tv.cur + 1];
+    const float4 q2 = nodes[4 * tv.cur + 2];
+    const float4 q3 = nodes[4 * tv.cur + 3];
+    // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
+    float a0 = __builtin_fmaf(q0.x, sl.ix, sl.ox), b0 = __builtin_fmaf(q0.w, sl.ix, sl.ox);
+    float a1 = __builtin_fmaf(q0.y, sl.iy, sl.oy), b1 = __builtin_fmaf(q1.x, sl.iy, sl.oy);
+    float a2 = __builtin_fmaf(q0.z, sl.iz, sl.oz), b2 = __builtin_fmaf(q1.y, sl.iz, sl.oz);
+    float tmin0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), 0.0f));
+    float tmax0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tv.best_t));
+    float c0 = __builtin_fmaf(q1.z, sl.ix, sl.ox), d0 = __builtin_fmaf(q2.y, sl.ix, sl.ox);
+    float c1 = __builtin_fmaf(q1.w, sl.iy, sl.oy), d1 = __builtin_fmaf(q2.z, sl.iy, sl.oy);
+    float c2 = __builtin_fmaf(q2.x, sl.iz, sl.oz), d2 = __builtin_fmaf(q2.w, sl.iz, sl.oz);
+    float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
+    float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), tv.best_t));
+    // an unused child slot (child index -1, inverted box) must never be entered: the slab
+    // arithmetic on its infinities would report a hit
+    const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.x) >= 0);
+    const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.y) >= 0);
+    int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
+    int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
+    if (hit0 && hit1) {
+        if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
+        stack[tv.sp * kBlock] = (uint32_t)r1;
+        tv.sp++;
+        tv.cur = r0;
+    } else if (hit0) {
+        tv.cur = r0;
+    } else if (hit1) {
+        tv.cur = r1;
+    } else {
+        trav_pop(tv, stack);
+    }
+}
+
+// Test the next primitive of the leaf under the cursor.
+RT_DEV void trav_leaf_step(const float4* __restrict__ prims, V3 ro, V3 rd, const uint32_t* __restrict__ stack, Trav& tv) {
+    const int first = tv.cur & 0x0fffffff;
+    const int left = (tv.cur >> 28) & 7;  // primitives after this one
+    intersect_record(prims, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
+    if (left == 0) trav_pop(tv, stack);
+    else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 1) << 28) | (uint32_t)(first + 1));
+}
+
+// Hit record of the winning primitive (raytracer.comp:354-358, 398-403, 454-461).
+RT_DEV void make_hit(const DeviceScene& sc, const float4* __restrict__ recs, int idx, float t, V3 ro, V3 rd, Hit& h,
+                     int& prim_id) {
+    const float4 A = recs[3 * idx + 0];
+    const float4 B = recs[3 * idx + 1];
+    const float4 C = recs[3 * idx + 2];
+    prim_id = __float_as_int(A.w);
+    const int matbits = __float_as_int(C.w);
+    h.t = t;
+    h.p = ro + t * rd;
+    V3 outward;
+    if (matbits < 0) {
+        h.mat = matbits & 0x7fffffff;
+        outward = (h.p - v3(A.x, A.y, A.z)) / B.x;
+    } else {
+        h.mat = matbits;
+        if (prim_id < sc.n_spheres + sc.n_triangles) {
+            const float4 n = sc.triangles[4 * (prim_id - sc.n_spheres) + 3];  // stored Triangle.normal
+            outward = v3(n.x, n.y, n.z);
+        } else {
+            outward = normalize(cross(v3(B.x, B.y, B.z), v3(C.x, C.y, C.z)));
+        }
+    }
+    h.front_face = dot(rd, outward) < 0.0f;  // set_face_normal, raytracer.comp:322-329
+    h.normal = h.front_face ? outward : -outward;
+}
+
+RT_DEV uint32_t pack_unorm8(float x) {
+    float c = g_clamp(x, 0.0f, 1.0f);  // NaN -> 0
+    return (uint32_t)__builtin_rintf(c * 255.0f);
+}
+
+// raytracer.comp:984-995: accumulate one frame's colour, write acc/count as B,G,R,A bytes
+RT_DEV uint32_t resolve_pixel(float4 a, int c) {
+    float d = (float)((c > 1) ? c : 1);
+    return pack_unorm8(a.z / d) | (pack_unorm8(a.y / d) << 8) | (pack_unorm8(a.x / d) << 16) | (pack_unorm8(a.w / d) << 24);
+}
+
+// get_ray, raytracer.comp:933-952: jittered primary ray through pixel (px, py).
+RT_DEV void generate_ray(const FrameArgs& fa, int px, int py, uint32_t& seed, V3& ro, V3& rd) {
+    const float aspect = (float)fa.width / (float)fa.height;  // raytracer.comp:187
+    float sx = rng_random(seed) - 0.5f;
+    float sy = rng_random(seed) - 0.5f;
+    float fx = (float)px + sx;
+    float fy = (float)py + sy;
+    float ndcX = 2.0f * fx / (float)fa.width - 1.0f;
+    float ndcY = 1.0f - 2.0f * fy / (float)fa.height;
+    V3 dc = normalize(v3(ndcX * aspect * fa.tan_half_fov, ndcY * fa.tan_half_fov, -1.0f));
+    const float* m = fa.view_inv;
+    V3 dw = v3(m[0] * dc.x + m[4] * dc.y + m[8] * dc.z + m[12] * 0.0f,
+               m[1] * dc.x + m[5] * dc.y + m[9] * dc.z + m[13] * 0.0f,
+               m[2] * dc.x + m[6] * dc.y + m[10] * dc.z + m[14] * 0.0f);
+    rd = normalize(dw);
+    ro = v3(fa.cam_pos[0], fa.cam_pos[1], fa.cam_pos[2]);
+}
+
+// Pixel slot -> image coordinates: slots walk 8x8 tiles row-major over the rows this
+// context owns; with a strip partition the owned rows are every strip_count-th strip.
+RT_DEV bool slot_to_pixel(const FrameArgs& fa, uint32_t slot, int& x, int& y) {
+    const uint32_t tile = slot >> 6, in = slot & 63u;
+    x = (int)(tile % (uint32_t)fa.tiles_x) * 8 + (int)(in & 7u);
+    const int r = (int)(tile / (uint32_t)fa.tiles_x) * 8 + (int)(in >> 3);
+    if (x >= fa.width || r >= fa.owned_rows) return false;
+    y = r;
+    if (fa.strip_rows > 0) y = ((r / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (r % fa.strip_rows);
+    return true;
+}
+
+// The second half of sample_light (raytracer.comp:617-626, 636-644, 662-671): what arrives
+// from light `ltype` (colour/strength lc) given the visibility search's result.
+RT_DEV void light_arrival(int ltype, float4 lc, int hit_idx, float hit_t, float s_d, V3 s_L, V3 normal, V3& Le, V3& Ldir,
+                          float& light_pdf) {
+    Le = v3(0.0f);
+    Ldir = normal;
+    light_pdf = 0.00001f;
+    if (ltype == 3 /* DIRECTIONAL */) {
+        if (hit_idx < 0) {
+            Ldir = s_L;
+            light_pdf = 1.0f;
+            Le = v3(lc.x, lc.y, lc.z);
+        }
+    } else if (hit_idx >= 0 && g_abs(s_d - hit_t) < 0.1f) {
+        float d2 = s_d * s_d;
+        Ldir = s_L;
+        light_pdf = (ltype == 1 /* SPHERE */) ? (1.0f / 2.0f / kPi) : 1.0f;
+        Le = g_clamp(v3(lc.x, lc.y, lc.z) * lc.w / d2, 0.0f, 1.0f);
+    }
+}
+
+// direct_light, raytracer.comp:870-881.  With no emission arriving (Le == 0: occluded,
+// facing away, no lights) the term is clamp(0 * fr * cos / pdf) = +0 whatever fr is (a NaN
+// clamps to 0 too), and the attenuation at bounce 0 is 1: nothing to add.
+RT_DEV V3 direct_term(const Material& mat, const Hit& h, V3 V, V3 Le, V3 Ldir, float light_pdf, V3 att) {
+    float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
+    float mat_pdf;
+    V3 fr = eval_mat(mat, Ldir, V, h, mat_pdf);
+    float pdf = power_heuristics(light_pdf, mat_pdf);
+    return g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
+}
+
+// The first half of sample_light (raytracer.comp:582-616, 633-635, 653-661): pick a light
+// by strength, sample a point on it.  Returns the kind of query that follows:
+//   0 = visibility search along s_L (distance s_d), 1 = no search, arrival known (AMBIENT:
+//   Ldir in s_L), 2 = no search, nothing arrives (DIRECTIONAL facing away), 3 = no search,
+//   the shader's undefined light types (Le = 1, L = 0, pdf = 0).
+RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, uint32_t& seed, int& light, V3& s_L, float& s_d) {
+    float rand_strength = rng_random(seed) * fa.lights_strength_sum;
+    int low = 0, high = fa.total_lights - 1;
+    while (low < high) {
+        int mid = (low + high) / 2;
+        if (rand_strength <= sc.lights[3 * mid + 2].y) high = mid; else low = mid + 1;
+    }
+    light = low;
+    const float4 lp = sc.lights[3 * low + 0];
+    const int ltype = __float_as_int(sc.lights[3 * low + 2].x);
+    s_d = 0.0f;
+    s_L = v3(0.0f);
+    if (ltype == 0 /* AMBIENT */) {
+        s_L = random_vec_on_hemisphere(h.normal, seed);
+        return 1;
+    }
+    if (ltype == 1 /* SPHERE */) {
+        V3 center = v3(lp.x, lp.y, lp.z);
+        V3 center_to_point = h.p - center;
+        V3 sphere_point = random_vec_on_hemisphere(normalize(center_to_point), seed) * lp.w + center;
+        V3 pts = sphere_point - h.p;
+        s_d = length(pts);
+        s_L = normalize(pts);
+        return 0;
+    }
+    if (ltype == 3 /* DIRECTIONAL */) {
+        V3 light_dir = -v3(lp.x, lp.y, lp.z);
+        if (dot(h.normal, light_dir) > 0.0f) {
+            s_L = light_dir;
+            return 0;
+        }
+        return 2;
+    }
+    if (ltype == 6 /* TRIANGLE */) {
+        const int ti = (int)lp.x;
+        const float4 t0 = sc.triangles[4 * ti + 0];
+        const float4 t1 = sc.triangles[4 * ti + 1];
+        const float4 t2 = sc.triangles[4 * ti + 2];
+        float e1 = g_sqrt(rng_random(seed));
+        float e2 = rng_random(seed);
+        V3 tri_point = (1.0f - e1) * v3(t0.x, t0.y, t0.z) + e1 * (1.0f - e2) * v3(t1.x, t1.y, t1.z) + e1 * e2 * v3(t2.x, t2.y, t2.z);
+        V3 pts = tri_point - h.p;
+        s_d = length(pts);
+        s_L = normalize(pts);
+        return 0;
+    }
+    // POINT / CONE / AREA fall through the shader's switch (raytracer.comp:628-651) and
+    // return vec3(1) with L and pdf never written; they are taken as zero.
+    return 3;
+}
+
+}  // namespace rtd

@@ -44,6 +44,12 @@ struct RtContext {
     uint32_t* d_path_hash = nullptr;
     uint32_t* d_counters = nullptr;  // 32 x u32, see FrameArgs::counters
 
+    // path state of the staged pipeline (allocated on first use, grown when needed)
+    void* d_pool = nullptr;
+    size_t pool_slots = 0;
+    uint32_t* d_active = nullptr;
+    size_t active_len = 0;
+
     std::string err;
 };
 
@@ -93,6 +99,58 @@ int upload_array(RtContext* c, void** dst, const void* src, size_t bytes, size_t
     RT_HIP(c, hipMalloc(dst, alloc));
     RT_HIP(c, hipMemsetAsync(*dst, 0, alloc, c->stream));
     if (bytes) RT_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+void free_pool(RtContext* c) {
+    if (c->d_pool) (void)hipFree(c->d_pool);
+    if (c->d_active) (void)hipFree(c->d_active);
+    c->d_pool = nullptr;
+    c->d_active = nullptr;
+    c->pool_slots = 0;
+    c->active_len = 0;
+}
+
+// Bytes of path state per slot: stage word, ctl, hit, and nine float4 arrays.
+constexpr size_t kPoolBytesPerSlot = 4 + 16 + 8 + 9 * 16;
+
+// One allocation carved into the PathPool arrays (16-byte arrays first, so every array is
+// aligned for its widest load).
+int ensure_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& pp) {
+    if (n_slots > c->pool_slots) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_pool) (void)hipFree(c->d_pool);
+        c->d_pool = nullptr;
+        c->pool_slots = 0;
+        size_t cap = (n_slots + 255) / 256 * 256;
+        RT_HIP(c, hipMalloc(&c->d_pool, cap * kPoolBytesPerSlot));
+        c->pool_slots = cap;
+    }
+    if (iterations + 2 > c->active_len) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_active) (void)hipFree(c->d_active);
+        c->d_active = nullptr;
+        c->active_len = 0;
+        size_t len = iterations + 2 + 256;
+        RT_HIP(c, hipMalloc((void**)&c->d_active, len * 4));
+        c->active_len = len;
+    }
+    const size_t cap = c->pool_slots;
+    char* p = (char*)c->d_pool;
+    auto take = [&](size_t bytes_per_slot) { char* r = p; p += cap * bytes_per_slot; return (void*)r; };
+    pp.ctl = (uint4*)take(16);
+    pp.ray_o = (float4*)take(16);
+    pp.ray_d = (float4*)take(16);
+    pp.att = (float4*)take(16);
+    pp.col = (float4*)take(16);
+    pp.pix = (float4*)take(16);
+    pp.hp = (float4*)take(16);
+    pp.hn = (float4*)take(16);
+    pp.vdir = (float4*)take(16);
+    pp.hit = (uint2*)take(8);
+    pp.stage = (uint32_t*)take(4);
+    pp.active = c->d_active;
+    pp.n_slots = (uint32_t)n_slots;
     return RT_OK;
 }
 
@@ -150,6 +208,7 @@ int rt_destroy(RtContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_framebuffer(c);
+    free_pool(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -332,6 +391,8 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         int v = atoi(q);
         if (v >= 1 && v <= 100) fa.exit_quota_pct = v;
     }
+    fa.accel = p.accel;
+    fa.stack_depth = c->bvh_depth + 2 < 4 ? 4 : (c->bvh_depth + 2 > rtd::kStackDepth ? rtd::kStackDepth : c->bvh_depth + 2);
     fa.accum = (float4*)c->d_accum;
     fa.counts = (int32_t*)c->d_counts;
     fa.bgra = (uint32_t*)c->d_bgra;
@@ -351,7 +412,38 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     if (fa.total_slots > 0) {
         bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
-        RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, c->cu_count, c->stream));
+        int refill_min = 16;
+        if (const char* q = getenv("RT_REFILL_MIN")) {  // tuning aid
+            int v = atoi(q);
+            if (v >= 1 && v <= 64) refill_min = v;
+        }
+        if (p.flags & RT_FLAG_POOLED) {
+            unsigned grid = 0;
+            RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
+            rtd::PathPool pp;
+            int rc = ensure_pool(c, (size_t)grid * (size_t)rtd::pool_slots_per_block(), 0, pp);
+            if (rc != RT_OK) return rc;
+            int burst = 8;
+            if (const char* q = getenv("RT_POOL_BURST")) {  // tuning aid
+                int v = atoi(q);
+                if (v >= 1 && v <= 1024) burst = v;
+            }
+            RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
+            RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, refill_min, burst, c->stream));
+        } else if (p.flags & RT_FLAG_WAVEFRONT) {
+            // every live path advances by one ray per iteration; a sample needs at most
+            // max_bounces + 1 path rays and one light query
+            long long iterations = (long long)p.spp * ((long long)p.max_bounces + 2);
+            if (iterations > (1ll << 20)) return fail(c, RT_ERR_TOO_LARGE, "spp x (max_bounces + 2) exceeds 2^20 launches pairs");
+            rtd::PathPool pp;
+            int rc = ensure_pool(c, fa.total_slots, (size_t)iterations, pp);
+            if (rc != RT_OK) return rc;
+            RT_HIP(c, hipMemsetAsync(c->d_active, 0, ((size_t)iterations + 2) * 4, c->stream));
+            RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
+            RT_HIP(c, rtd::launch_wavefront(sc, fa, pp, p.accel, stats, (int)iterations, refill_min, c->cu_count, c->stream));
+        } else {
+            RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, c->cu_count, c->stream));
+        }
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
     c->timed = true;

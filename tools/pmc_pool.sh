@@ -1,0 +1,10 @@
+# PMC passes over tools/run_frames.py for one pipeline.  Usage: tools/pmc_pool.sh <workload> <mode> <outdir>
+export TMPDIR=/tmp
+wl=${1:-c3}; mode=${2:-pooled}; out=${3:-gpurun_out/pmc_$mode}
+mkdir -p $out
+run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 tools/run_frames.py $wl 2 $mode > "$out/$name.log" 2>&1 || { echo "FAILED $name"; return 1; }; }
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE && \
+run sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS && \
+run tc1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum && \
+run fetch FETCH_SIZE && run write WRITE_SIZE
+python3 tools/pmc_summary.py $out _kernel
