@@ -103,6 +103,10 @@ def main() -> None:
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     main_stream = torch.cuda.current_stream(dev)
+    exchange = None
+    if collective and partition == "strips":
+        exchange = parallel.StripExchange([acc, cnt, bgra], H, STRIP_ROWS, world, rank, include_self=args.force_collective)
+    packed = torch.cuda.Event()
 
     def step(frame: int, ev=None) -> None:
         if partition == "samples":
@@ -128,9 +132,15 @@ def main() -> None:
         if ev is not None:
             ev[1].record(rt_stream)
         if collective:
+            # own rows are copied out first; the next frame's kernel (own rows only) may then run
+            # while the all-gather moves the copies and the other ranks' rows are written back
             main_stream.wait_stream(rt_stream)
-            parallel.gather_strips([acc, cnt, bgra], H, STRIP_ROWS, world, rank, force=args.force_collective)
-            rt_stream.wait_stream(main_stream)
+            exchange.pack()
+            packed.record(main_stream)
+            rt_stream.wait_event(packed)
+            exchange.exchange()
+            if args.force_collective:  # the one-rank self-test writes its own rows back too
+                rt_stream.wait_stream(main_stream)
 
     def fence() -> None:
         ctx.sync()

@@ -195,3 +195,73 @@ def test_error_codes(ctx, star):
             Context(99)
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------------------- pipelines
+# The library has three schedules of the same per-path program: the single persistent kernel
+# (default), the staged one (RT_FLAG_WAVEFRONT: one search launch + one shading launch per
+# ray generation) and the pooled one (RT_FLAG_POOLED: persistent workgroups regrouping four
+# paths per lane through LDS queues).  A pixel's arithmetic never depends on the schedule,
+# so all three must agree bit for bit — with each other at any size, and with the oracle.
+
+PIPELINES = {"staged": capi.RT_FLAG_WAVEFRONT, "pooled": capi.RT_FLAG_POOLED}
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+def test_pipeline_flat_star_bit_exact_vs_oracle(ctx, star, pipeline):
+    from helpers import DEBUG_FLAGS
+    W, H = 96, 54
+    o = oracle_frames(star, W, H, spp=2, max_bounces=6, frames=2)
+    g = gpu_frames(ctx, star, W, H, spp=2, max_bounces=6, frames=2, accel=capi.RT_ACCEL_FLAT,
+                   flags=DEBUG_FLAGS | PIPELINES[pipeline])
+    assert_identical(g, o)
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+@pytest.mark.parametrize("kind", ["ambient", "directional", "mixed", "nolights"])
+def test_pipeline_light_types_equal_single_kernel(ctx, pipeline, kind):
+    from helpers import DEBUG_FLAGS
+    s = _custom_scene(kind)
+    W, H = 72, 40
+    a = gpu_frames(ctx, s, W, H, spp=3, max_bounces=5, accel=capi.RT_ACCEL_BVH)
+    b = gpu_frames(ctx, s, W, H, spp=3, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | PIPELINES[pipeline])
+    assert_identical(b, a)
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+@pytest.mark.parametrize("size", [(1, 1), (9, 17), (130, 5)])
+def test_pipeline_ragged_sizes_and_strips(ctx, star, pipeline, size):
+    from helpers import DEBUG_FLAGS
+    W, H = size
+    fl = DEBUG_FLAGS | PIPELINES[pipeline]
+    a = gpu_frames(ctx, star, W, H, spp=2, max_bounces=3, accel=capi.RT_ACCEL_BVH)
+    b = gpu_frames(ctx, star, W, H, spp=2, max_bounces=3, accel=capi.RT_ACCEL_BVH, flags=fl)
+    assert_identical(b, a)
+    if H >= 5:
+        a = gpu_frames(ctx, star, W, H, spp=1, max_bounces=3, accel=capi.RT_ACCEL_BVH, strip=(2, 2, 1))
+        b = gpu_frames(ctx, star, W, H, spp=1, max_bounces=3, accel=capi.RT_ACCEL_BVH, strip=(2, 2, 1), flags=fl)
+        assert_identical(b, a)
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_full_size_frames_agree_across_pipelines(ctx, workload):
+    """BASELINE.json's full sizes (1920x1080; C2: 4 spp x 20 bounces on the star scene, C3: 16 spp
+    x 4 bounces on the teapot scene), too large for the oracle: the single kernel and the pooled
+    schedule are independent orders of execution of the same 2 million pixels and must give the
+    same accumulated floats, counts, BGRA8 bytes, per-pixel path hashes and ray count; two
+    accumulated frames also check that frame N+1 sees frame N's accumulation."""
+    from helpers import DEBUG_FLAGS
+    from raytracer_amd.workloads import WORKLOADS, workload_camera
+    preset, W, H, spp, mb, _ = WORKLOADS[workload]
+    s = Scene(preset)
+    cam = workload_camera(workload, W, H)
+    a = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam)
+    b = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+    assert_identical(b, a)
+    assert (a["counts"] == 2).all()
+    assert np.isfinite(a["accum"]).all()
+    # every pixel's BGRA8 byte is the rounded mean of its accumulated colour (raytracer.comp:992-995)
+    mean = np.clip(a["accum"] / 2.0, 0.0, 1.0)
+    expect = np.rint(mean * np.float32(255.0)).astype(np.uint32)
+    packed = expect[..., 2] | (expect[..., 1] << 8) | (expect[..., 0] << 16) | (expect[..., 3] << 24)
+    assert np.array_equal(packed, a["bgra"].view(np.uint32).reshape(H, W))
