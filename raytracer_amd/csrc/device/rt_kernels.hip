@@ -25,7 +25,7 @@ namespace {
 // next ray while the stragglers keep their cursor, stack and best hit and resume on the
 // next call: a long traversal no longer holds 63 idle lanes hostage.
 template <bool STATS>
-RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, Trav& tv, bool wants_result,
+RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, Trav& tv, float t_occl, bool wants_result,
                             int exit_quota, uint32_t& n_nodes, uint32_t& n_tests, uint32_t& n_iters,
                             unsigned long long& wave_iters) {
     // Slab arithmetic runs on a direction with no zero component; the boxes are padded on
@@ -91,12 +91,17 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __res
                 if (STATS) { n_tests++; n_iters++; }
                 if (left == 0) trav_pop(tv, stack);
                 else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 1) << 28) | (uint32_t)(first + 1));
+                // a light-visibility ray is decided once something lies clearly in front of the light
+                if (tv.best_t < t_occl) tv.cur = kTravDone;
             }
         }
     }
 }
 
-enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2 };
+// ST_BOUNCE: the shading point is in `sh` and its direct term is done; sample_mat + eval_mat follow.
+// A lane that owes a direct term evaluates the BSDF for it in one round and for its bounce in
+// the next, so that a round has ONE eval_mat site shared by both kinds of lanes.
+enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2, ST_BOUNCE = 3 };
 
 template <int ACCEL, bool STATS>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc, const FrameArgs fa) {
@@ -118,6 +123,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
     sh.p = v3(0.0f); sh.normal = v3(0.0f); sh.mat = 0; sh.t = 0.0f; sh.front_face = false;
     V3 s_L = v3(0.0f);
     float s_d = 0.0f;
+    float t_occl = -kInf;  // light-visibility rays: a hit nearer than this settles the query (see below)
     int s_light = 0;
     // counters
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, n_iters = 0;
@@ -218,6 +224,21 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             tv.best_t = kInf;
             tv.best_prio = 0x7fffffff;
             tv.best_idx = -1;
+            // A light-visibility query only asks whether the nearest hit lies within 0.1 of the
+            // sampled point's distance s_d (raytracer.comp:617-626, 662-671), or, for a
+            // directional light, whether anything is hit at all (636-644).  Its search is
+            // therefore bounded to t < s_d + 0.2 and ends at the first hit nearer than s_d - 0.2:
+            // either way the comparison the shader makes comes out the same.  Not when the
+            // per-pixel hash of nearest-hit ids is recorded, which needs the true nearest hit.
+            t_occl = -kInf;
+            if (ACCEL == 1 && state == ST_TRACE_LIGHT && !(fa.flags & 2u)) {
+                if (__float_as_int(sc.lights[3 * s_light + 2].x) == 3 /* DIRECTIONAL */) {
+                    t_occl = kInf;
+                } else {
+                    t_occl = s_d - 0.2f;
+                    tv.best_t = s_d + 0.2f;
+                }
+            }
             if (ACCEL != 1) {
                 trace_flat(sc, qo, qd, tv.best_t, tv.best_idx);
                 if (STATS) n_tests += (uint32_t)sc.n_prims;
@@ -228,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             const int busy_lanes = __popcll(__ballot(state != ST_IDLE));
             int quota = (busy_lanes * fa.exit_quota_pct + 99) / 100;
             quota = quota < 1 ? 1 : quota;
-            trace_bvh_steps<STATS>(sc, qo, qd, &s_stack[tid], tv, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
+            trace_bvh_steps<STATS>(sc, qo, qd, &s_stack[tid], tv, t_occl, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
         }
         if (STATS) stamp2 = (long long)__builtin_readcyclecounter();
         // lanes whose search is still running keep their state and skip the continuation
@@ -239,6 +260,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
         bool need_shade = false, have_direct = false, end_sample = false;
         Hit h = sh;
         const bool is_primary = (ready && state == ST_TRACE_PATH && sample == 0 && bounce == 0);
+        const bool traced = ready && (state == ST_TRACE_PATH || state == ST_TRACE_LIGHT);
         V3 Le = v3(0.0f), Ldir = v3(0.0f);
         float light_pdf = 0.0f;
         int prim_id = -1;
@@ -349,9 +371,11 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                     need_shade = true;
                 }
             }
+        } else if (ready && state == ST_BOUNCE) {
+            need_shade = true;
         }
         if (is_primary && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[py * fa.width + px] = prim_id;
-        if (ready) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
+        if (traced) phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
         long long sp1 = 0, sp2 = 0, sp3 = 0, sp4 = 0;
         if (STATS) sp1 = (long long)__builtin_readcyclecounter();
@@ -361,29 +385,33 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             // direct_light, raytracer.comp:870-881.  With no emission arriving (Le == 0: occluded,
             // facing away, no lights) the term is clamp(0 * fr * cos / pdf) = +0 whatever fr is
             // (a NaN clamps to 0 too), and the attenuation at bounce 0 is 1: nothing to add.
-            if (have_direct && (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f)) {
-                float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
-                float mat_pdf;
-                V3 fr = eval_mat(mat, Ldir, V, h, mat_pdf);
-                float pdf = power_heuristics(light_pdf, mat_pdf);
-                col = col + g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
-            }
+            const bool direct_now = have_direct && (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f);
             if (STATS) sp2 = (long long)__builtin_readcyclecounter();
             // indirect bounce, raytracer.comp:913-921
-            V3 bounce_dir = sample_mat(mat, V, h, seed);
+            V3 bounce_dir = v3(0.0f);
+            if (!direct_now) bounce_dir = sample_mat(mat, V, h, seed);
             if (STATS) sp3 = (long long)__builtin_readcyclecounter();
+            const V3 Lq = direct_now ? Ldir : bounce_dir;
             float mat_pdf;
-            V3 fr = eval_mat(mat, bounce_dir, V, h, mat_pdf);
-            float cos_theta = g_abs(dot(h.normal, bounce_dir));
-            att = att * g_max(v3(0.0f), fr * cos_theta / g_max(0.00001f, mat_pdf));
-            ro = h.p;
-            rd = bounce_dir;
-            qo = ro;
-            qd = rd;
-            fresh = true;
-            bounce++;
-            state = ST_TRACE_PATH;
-            if (bounce > fa.max_bounces) end_sample = true;
+            V3 fr = eval_mat(mat, Lq, V, h, mat_pdf);
+            if (direct_now) {
+                float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
+                float pdf = power_heuristics(light_pdf, mat_pdf);
+                col = col + g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
+                sh = h;
+                state = ST_BOUNCE;
+            } else {
+                float cos_theta = g_abs(dot(h.normal, bounce_dir));
+                att = att * g_max(v3(0.0f), fr * cos_theta / g_max(0.00001f, mat_pdf));
+                ro = h.p;
+                rd = bounce_dir;
+                qo = ro;
+                qd = rd;
+                fresh = true;
+                bounce++;
+                state = ST_TRACE_PATH;
+                if (bounce > fa.max_bounces) end_sample = true;
+            }
         }
         if (STATS) {
             sp4 = (long long)__builtin_readcyclecounter();

@@ -265,3 +265,17 @@ def test_full_size_frames_agree_across_pipelines(ctx, workload):
     expect = np.rint(mean * np.float32(255.0)).astype(np.uint32)
     packed = expect[..., 2] | (expect[..., 1] << 8) | (expect[..., 0] << 16) | (expect[..., 3] << 24)
     assert np.array_equal(packed, a["bgra"].view(np.uint32).reshape(H, W))
+
+
+@pytest.mark.parametrize("kind", ["teapot", "directional", "mixed"])
+def test_bounded_light_queries_leave_the_image_unchanged(ctx, teapot, kind):
+    """Without RT_FLAG_PATH_HASH the single kernel bounds its light-visibility searches (they stop
+    at the first occluder and ignore anything beyond the light); the accumulated image must
+    not change by a bit, only the nearest-hit ids those searches would have reported."""
+    s = teapot if kind == "teapot" else _custom_scene(kind)
+    W, H = 160, 90
+    exact = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH)
+    fast = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH, flags=capi.RT_FLAG_PRIMARY_IDS)
+    assert bit_equal_pixels(exact["accum"], fast["accum"]).all()
+    assert np.array_equal(exact["counts"], fast["counts"]) and np.array_equal(exact["bgra"], fast["bgra"])
+    assert np.array_equal(exact["primary_ids"], fast["primary_ids"]) and exact["total_rays"] == fast["total_rays"]
