@@ -115,7 +115,6 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
     uint32_t seed = 0;
     int px = 0, py = 0, sample = 0, bounce = 0;
     V3 ro = v3(0.0f), rd = v3(0.0f, 0.0f, 1.0f);  // path ray
-    V3 qo = ro, qd = rd;                            // ray handed to the nearest-hit search
     V3 att = v3(1.0f), col = v3(0.0f), pix = v3(0.0f);
     uint32_t phash = 0;
     // saved across a light-visibility search
@@ -132,7 +131,8 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
     // wave-uniform pixel reserve
     uint32_t res_next = 0, res_left = 0;
     bool exhausted = false;
-    // resumable search state; `fresh` marks a ray (qo, qd) whose search has not started yet
+    // resumable search state; `fresh` marks a ray whose search has not started yet.  The ray handed
+    // to the search is the path ray (ro, rd), or for a light query (sh.p, s_L)
     Trav tv;
     tv.cur = kTravDone; tv.sp = 0; tv.best_t = kInf; tv.best_prio = 0x7fffffff; tv.best_idx = -1;
     bool fresh = false;
@@ -200,8 +200,6 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                        m[2] * dc.x + m[6] * dc.y + m[10] * dc.z + m[14] * 0.0f);
             rd = normalize(dw);
             ro = v3(fa.cam_pos[0], fa.cam_pos[1], fa.cam_pos[2]);
-            qo = ro;
-            qd = rd;
             att = v3(1.0f);
             col = v3(0.0f);
             bounce = 0;
@@ -216,6 +214,8 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
 
         // ------------------------------------------------------------------ nearest-hit search
         if (STATS) stamp1 = (long long)__builtin_readcyclecounter();
+        const V3 qo = (state == ST_TRACE_LIGHT) ? sh.p : ro;
+        const V3 qd = (state == ST_TRACE_LIGHT) ? s_L : rd;
         if (state != ST_IDLE && fresh) {
             fresh = false;
             n_rays++;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
         const int hit_idx = tv.best_idx;
         // ------------------------------------------------------------------ continuation
         bool need_shade = false, have_direct = false, end_sample = false;
-        Hit h = sh;
+        Hit& h = sh;  // a lane that takes a new path hit no longer needs the shading point it kept
         const bool is_primary = (ready && state == ST_TRACE_PATH && sample == 0 && bounce == 0);
         const bool traced = ready && (state == ST_TRACE_PATH || state == ST_TRACE_LIGHT);
         V3 Le = v3(0.0f), Ldir = v3(0.0f);
@@ -295,7 +295,6 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                 const Material mat = load_material(sc.materials, h.mat);
                 if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
                     ro = h.p;
-                    qo = ro;
                     fresh = true;
                     bounce++;
                     if (bounce > fa.max_bounces) end_sample = true;
@@ -358,10 +357,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                             Le = v3(1.0f);
                         }
                         if (search) {
-                            sh = h;
                             s_light = low;
-                            qo = h.p;
-                            qd = s_L;
                             fresh = true;
                             state = ST_TRACE_LIGHT;
                             need_shade = false;
@@ -388,25 +384,31 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             const bool direct_now = have_direct && (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f);
             if (STATS) sp2 = (long long)__builtin_readcyclecounter();
             // indirect bounce, raytracer.comp:913-921
-            V3 bounce_dir = v3(0.0f);
-            if (!direct_now) bounce_dir = sample_mat(mat, V, h, seed);
+            // Registers are scarcest across eval_mat: only the direction, its cosine with the
+            // normal, and (parked in the light-query variables, which this lane no longer needs)
+            // the arriving radiance and the light's pdf stay live.
+            V3 Lq;
+            if (direct_now) {
+                Lq = Ldir;
+                s_L = Le;
+                s_d = light_pdf;
+            } else {
+                Lq = sample_mat(mat, V, h, seed);
+            }
             if (STATS) sp3 = (long long)__builtin_readcyclecounter();
-            const V3 Lq = direct_now ? Ldir : bounce_dir;
+            const float cos_raw = dot(h.normal, Lq);
             float mat_pdf;
             V3 fr = eval_mat(mat, Lq, V, h, mat_pdf);
             if (direct_now) {
-                float cos_theta = g_max(0.0f, dot(h.normal, Ldir));
-                float pdf = power_heuristics(light_pdf, mat_pdf);
-                col = col + g_clamp(Le * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
-                sh = h;
+                float cos_theta = g_max(0.0f, cos_raw);
+                float pdf = power_heuristics(s_d, mat_pdf);
+                col = col + g_clamp(s_L * fr * cos_theta / pdf, 0.0f, 1.0f) * att;
                 state = ST_BOUNCE;
             } else {
-                float cos_theta = g_abs(dot(h.normal, bounce_dir));
+                float cos_theta = g_abs(cos_raw);
                 att = att * g_max(v3(0.0f), fr * cos_theta / g_max(0.00001f, mat_pdf));
                 ro = h.p;
-                rd = bounce_dir;
-                qo = ro;
-                qd = rd;
+                rd = Lq;
                 fresh = true;
                 bounce++;
                 state = ST_TRACE_PATH;
