@@ -3,7 +3,7 @@
 per-launch averages of every counter."""
 import csv, glob, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-kern = sys.argv[2] if len(sys.argv) > 2 else "render_kernel"
+kern = sys.argv[2] if len(sys.argv) > 2 else "render_kernel<1, false>"  # the timed kernel, not its instrumented variant
 acc = collections.defaultdict(list)
 for f in sorted(glob.glob(root + "/*/*/*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
