@@ -82,6 +82,11 @@ struct PathPool {
     float4* vdir;   // direction of the path ray that reached the shading point
     uint32_t* active;  // [iterations + 1] slots still in flight at the start of each iteration
     uint32_t n_slots;
+    // pooled pipeline (hot state in LDS): per slot 4 float4 of cold state (pixel sum | normal, light
+    // distance | path direction, light index | material bits), per lane an overflow area for
+    // traversal stack entries beyond those kept in LDS
+    float4* cold;
+    uint32_t* stack_overflow;
 };
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
@@ -91,9 +96,11 @@ hipError_t launch_wavefront(const DeviceScene& sc, const FrameArgs& fa, const Pa
                             int refill_min, int cu_count, hipStream_t stream);
 // The pooled pipeline: one persistent launch, path slots regrouped through LDS queues.
 int pool_slots_per_block();
+int pool_overflow_per_lane();
+int pool_threads_per_block();
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, hipStream_t stream);
+                       int refill_min, int burst, int job_min, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);
 

@@ -25,7 +25,7 @@ namespace {
 // next ray while the stragglers keep their cursor, stack and best hit and resume on the
 // next call: a long traversal no longer holds 63 idle lanes hostage.
 template <bool STATS>
-RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __restrict__ stack, Trav& tv, float t_occl, bool wants_result,
+RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack stack, Trav& tv, float t_occl, bool wants_result,
                             int exit_quota, uint32_t& n_nodes, uint32_t& n_tests, uint32_t& n_iters,
                             unsigned long long& wave_iters) {
     // Slab arithmetic runs on a direction with no zero component; the boxes are padded on
@@ -72,7 +72,7 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, uint32_t* __res
                 int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
                 if (hit0 && hit1) {
                     if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
-                    stack[tv.sp * kBlock] = (uint32_t)r1;
+                    stack.put(tv.sp, (uint32_t)r1);
                     tv.sp++;
                     tv.cur = r0;
                 } else if (hit0) {
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             const int busy_lanes = __popcll(__ballot(state != ST_IDLE));
             int quota = (busy_lanes * fa.exit_quota_pct + 99) / 100;
             quota = quota < 1 ? 1 : quota;
-            trace_bvh_steps<STATS>(sc, qo, qd, &s_stack[tid], tv, t_occl, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
+            trace_bvh_steps<STATS>(sc, qo, qd, LdsStack{&s_stack[tid]}, tv, t_occl, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
         }
         if (STATS) stamp2 = (long long)__builtin_readcyclecounter();
         // lanes whose search is still running keep their state and skip the continuation

@@ -1,6 +1,6 @@
 // rt_pool.hip — the pooled form of the path tracer for gfx950 (MI355X): one persistent
-// launch per frame in which every workgroup owns a pool of kPool path slots (four per lane)
-// and regroups them continuously through queues in LDS.
+// launch per frame in which every workgroup owns a pool of kPool path slots (two per lane),
+// keeps their hot state in LDS and regroups them continuously through queues in LDS.
 //
 // One frame = one execution of shaders/raytracer.comp::main for every pixel this context
 // owns (raytracer.comp:956-996).  A slot carries one pixel: its samples and bounces are
@@ -11,17 +11,21 @@
 // Why: with one path per lane (rt_kernels.hip) a wave's 64 paths disagree about what to do
 // next, and most vector instructions run with most lanes masked off; with one launch per
 // stage (rt_wavefront.hip) a 1080p frame has too few rays per launch to fill this chip.
-// Here a workgroup keeps 1024 paths in flight for its 256 lanes.  Slots that wait for the
+// Here a workgroup keeps 512 paths in flight for its 256 lanes.  Slots that wait for the
 // same kind of work queue up in LDS (search, first-bounce result, later-bounce result,
 // light-query result, sample end); a wave either
 //   * shades: pops 64 slots of ONE kind and runs that stage for all of them, or
 //   * searches: its lanes walk the BVH for 64 rays, and a lane whose ray has ended stores
 //     the result, queues the slot for its stage and pops the next waiting ray.
-// Path state lives in device memory in a region private to the workgroup (PathPool,
-// slot = blockIdx.x * kPool + local index), so hand-offs between the workgroup's waves need
+// Hot path state (RNG, pixel, counters, ray, attenuation, sample radiance, hash, hit: 72 B
+// per slot) lives in LDS, structure of arrays; what is touched once per sample or per
+// light query (pixel sum, light-query record: 64 B per slot) lives in device memory in a
+// region private to the workgroup.  Hand-offs between the workgroup's waves need
 // workgroup-scope ordering only: state stores, release fence, LDS queue entry; the popping
 // wave reads the entry, acquire fence, state loads.  No wave ever waits for another wave
 // except for the few instructions between a queue reservation and its entry store.
+// Traversal stacks keep kShortStack entries per lane in LDS; deeper entries (rare) go to
+// a lane-private overflow area in device memory.
 #include "rt_stages.h"
 
 #include <cstdlib>
@@ -30,28 +34,93 @@ namespace rtd {
 
 namespace {
 
-#ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 1024
+#ifndef RT_POOL_THREADS
+#define RT_POOL_THREADS 768
 #endif
-constexpr int kPool = RT_POOL_SLOTS;  // path slots per workgroup
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS (2 * RT_POOL_THREADS)
+#endif
+#ifndef RT_POOL_STACK
+#define RT_POOL_STACK 8
+#endif
+#ifndef RT_POOL_WAVES_PER_SIMD
+#define RT_POOL_WAVES_PER_SIMD 3
+#endif
+constexpr int kThreads = RT_POOL_THREADS;  // threads per workgroup (one workgroup per CU at 768)
+constexpr int kWaves = kThreads / 64;
+constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of kWaves, <= 4096)
+constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
+constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
+constexpr int kOverflow = kStackDepth;  // entries per lane of the overflow area
 enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_LIGHT = 3, Q_END = 4, kQueues = 5 };
+constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kGuardLimit = 1u << 22;  // consecutive outer iterations without any work
 
 struct PoolLds {
-    uint16_t items[kQueues][kPool];  // rings; an entry is a local slot index (| kind << 12 in Q_SEARCH), kEmpty when free
+    // hot path state, one array per field
+    uint32_t seed[kPool], pixel[kPool], cnt[kPool];  // cnt = sample << 16 | bounce
+    float ro[3][kPool], rd[3][kPool], att[3][kPool], col[3][kPool];
+    uint32_t phash[kPool];
+    float hit_t[kPool];
+    int32_t hit_idx[kPool];
+    // queues
+    uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
     uint32_t count[kQueues];         // entries published and not yet claimed
     uint32_t head[kQueues];          // next ring position to pop
     uint32_t tail[kQueues];          // next ring position to push
     uint32_t live;                   // slots that still carry a pixel
+    uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
     uint32_t abort;                  // set when a bound on waiting was exceeded (never in a correct run)
+};
+
+// Accessor of slot i: hot fields in LDS, cold record (4 float4: pixel sum | normal, s_d |
+// path direction, light | material bits) in device memory.
+struct PoolSlot {
+    PoolLds& L;
+    float4* cold;
+    uint32_t i;
+    RT_DEV void get_ctl(uint32_t& seed, uint32_t& pixel, uint32_t& sample, int& bounce) const {
+        seed = L.seed[i]; pixel = L.pixel[i];
+        const uint32_t c = L.cnt[i];
+        sample = c >> 16; bounce = (int)(c & 0xffffu);
+    }
+    RT_DEV void put_ctl(uint32_t seed, uint32_t pixel, uint32_t sample, int bounce) const {
+        L.seed[i] = seed; L.pixel[i] = pixel; L.cnt[i] = (sample << 16) | (uint32_t)bounce;
+    }
+    RT_DEV V3 get_att(uint32_t& phash) const { phash = L.phash[i]; return v3(L.att[0][i], L.att[1][i], L.att[2][i]); }
+    RT_DEV void put_att(V3 a, uint32_t phash) const { L.att[0][i] = a.x; L.att[1][i] = a.y; L.att[2][i] = a.z; L.phash[i] = phash; }
+    RT_DEV V3 get_ro() const { return v3(L.ro[0][i], L.ro[1][i], L.ro[2][i]); }
+    RT_DEV V3 get_rd() const { return v3(L.rd[0][i], L.rd[1][i], L.rd[2][i]); }
+    RT_DEV void put_ro(V3 v) const { L.ro[0][i] = v.x; L.ro[1][i] = v.y; L.ro[2][i] = v.z; }
+    RT_DEV void put_rd(V3 v) const { L.rd[0][i] = v.x; L.rd[1][i] = v.y; L.rd[2][i] = v.z; }
+    RT_DEV void get_hit(float& t, int& idx) const { t = L.hit_t[i]; idx = L.hit_idx[i]; }
+    RT_DEV V3 get_col() const { return v3(L.col[0][i], L.col[1][i], L.col[2][i]); }
+    RT_DEV void put_col(V3 v) const { L.col[0][i] = v.x; L.col[1][i] = v.y; L.col[2][i] = v.z; }
+    RT_DEV V3 get_pix() const { return xyz(cold[0]); }
+    RT_DEV void put_pix(V3 v) const { cold[0] = f4(v, 0.0f); }
+    RT_DEV void put_stage(uint32_t) const {}
+    // bounds of a light query's search, kept in the hit fields until the search overwrites them
+    RT_DEV void put_search_bounds(float t_max, float t_occl) const { L.hit_t[i] = t_max; L.hit_idx[i] = __float_as_int(t_occl); }
+    RT_DEV void put_light_query(const LightQuery& q) const {
+        cold[1] = f4(q.normal, q.s_d);
+        cold[2] = f4(q.vdir, __uint_as_float((uint32_t)q.light));
+        cold[3] = make_float4(__uint_as_float((uint32_t)q.mat | (q.front_face ? 0x80000000u : 0u)), 0.0f, 0.0f, 0.0f);
+    }
+    RT_DEV void get_light_query(LightQuery& q) const {
+        const float4 n = cold[1], v = cold[2];
+        const uint32_t mbits = __float_as_uint(cold[3].x);
+        q.normal = xyz(n); q.s_d = n.w;
+        q.vdir = xyz(v); q.light = (int)__float_as_uint(v.w);
+        q.mat = (int)(mbits & 0x7fffffffu); q.front_face = (mbits >> 31) != 0u;
+    }
 };
 
 RT_DEV uint32_t lds_peek(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
-// device memory) is visible to the workgroup before the entries can be claimed.
+// LDS and device memory) is visible to the workgroup before the entries can be claimed.
 RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
@@ -60,20 +129,21 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     uint32_t pos = 0;
     if (lane_id() == leader) pos = atomicAdd(&L.tail[q], n);
     pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader);
-    if (want) *(volatile uint16_t*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kPool - 1)] = (uint16_t)item;
+    if (want) *(volatile uint16_t*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane_id() == leader) atomicAdd(&L.count[q], n);
 }
 
-// Claim up to one entry for each lane of `takers` (in lane order).  Returns the number of
-// entries claimed; `got` tells a lane whether `item` is valid.
-RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t& item, bool& got) {
+// Claim up to one entry for each lane of `takers` (in lane order), but nothing if fewer than
+// `at_least` are there.  Returns the number of entries claimed; `got` tells a lane whether
+// `item` is valid.
+RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t at_least, uint32_t& item, bool& got) {
     got = false;
     const uint32_t want = (uint32_t)__popcll(takers);
     uint32_t n = 0, pos = 0;
     if (want != 0u && lane_id() == 0) {
         uint32_t c = lds_peek(&L.count[q]);
-        while (c != 0u) {
+        while (c != 0u && c >= at_least) {
             const uint32_t take = c < want ? c : want;
             const uint32_t old = atomicCAS(&L.count[q], c, c - take);
             if (old == c) { n = take; break; }
@@ -86,7 +156,7 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     if (n == 0u) return 0u;
     const uint32_t rank = (uint32_t)__popcll(takers & lanes_below());
     if (((takers >> lane_id()) & 1ull) && rank < n) {
-        volatile uint16_t* e = &L.items[q][(pos + rank) & (kPool - 1)];
+        volatile uint16_t* e = &L.items[q][(pos + rank) & (kRing - 1)];
         uint32_t v = *e, tries = 0;
         while (v == kEmpty && ++tries < kSpinLimit) v = *e;  // the pusher is between its reservation and its store
         if (v == kEmpty) atomicExch(&L.abort, 1u);
@@ -98,36 +168,48 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     return n;
 }
 
-// Give the asking lanes' slots their next pixel from the frame's pixel counter (seed:
-// raytracer.comp:959-961; first primary ray: get_ray, raytracer.comp:933-952) and queue
-// them for the search.  A slot that finds the frame exhausted dies.
-RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, const PathPool& pp, uint32_t slot_base, bool need, uint32_t local) {
+// Give the asking lanes' slots their next pixel and queue them for the search.  Pixel slots
+// of the frame come from the workgroup's reserve, refilled kChunk at a time from the frame's
+// counter (one global atomic per kChunk pixels; the reserve is handed out under a small LDS
+// lock, taken a few hundred times per frame).  A slot that finds the frame exhausted dies.
+RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool need, uint32_t local) {
     bool started = false, dead = false;
     for (;;) {
         const unsigned long long m = __ballot(need);
         if (m == 0ull) break;
         const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(&fa.counters[0], (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        const uint32_t n = (uint32_t)__popcll(m);
+        uint32_t b1 = 0, c1 = 0, b2 = 0;
+        if (lane_id() == leader) {
+            while (atomicCAS(&L.res_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t next = *(volatile uint32_t*)&L.res_next, end = *(volatile uint32_t*)&L.res_end;
+            const uint32_t avail = end - next;
+            b1 = next;
+            c1 = avail < n ? avail : n;
+            next += c1;
+            if (c1 < n) {
+                b2 = atomicAdd(&fa.counters[0], kChunk);
+                next = b2 + (n - c1);
+                end = b2 + kChunk;
+            }
+            *(volatile uint32_t*)&L.res_next = next;
+            *(volatile uint32_t*)&L.res_end = end;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            atomicExch(&L.res_lock, 0u);
+        }
+        b1 = (uint32_t)__builtin_amdgcn_readlane((int)b1, leader);
+        c1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, leader);
+        b2 = (uint32_t)__builtin_amdgcn_readlane((int)b2, leader);
         if (need) {
-            const uint32_t mine = base + (uint32_t)__popcll(m & lanes_below());
+            const uint32_t rank = (uint32_t)__popcll(m & lanes_below());
+            const uint32_t mine = rank < c1 ? b1 + rank : b2 + (rank - c1);
             int x, y;
             if (mine >= fa.total_slots) {
                 need = false;
                 dead = true;
             } else if (slot_to_pixel(fa, mine, x, y)) {
-                const uint32_t s = slot_base + local;
-                uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
-                V3 ro, rd;
-                generate_ray(fa, x, y, seed, ro, rd);
-                pp.ctl[s] = make_uint4(seed, (uint32_t)(y * fa.width + x), 0u, 0u);
-                pp.ray_o[s] = f4(ro, 0.0f);
-                pp.ray_d[s] = f4(rd, 0.0f);
-                pp.att[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-                pp.col[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                pp.pix[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                pp.stage[s] = WF_PATH_FIRST;
+                start_pixel(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y);
                 need = false;
                 started = true;
             }
@@ -140,32 +222,36 @@ RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, const PathPool& pp, uin
 }
 
 template <int ACCEL, bool STATS>
-__global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
-                                                         int burst) {
+__global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
+                                                         int burst, int job_min) {
     __shared__ PoolLds L;
-    extern __shared__ uint32_t s_stack[];  // [stack_depth][kBlock]
+    extern __shared__ uint32_t s_stack[];  // [kShortStack][kThreads]
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint32_t slot_base = blockIdx.x * (uint32_t)kPool;
+    float4* const cold_base = pp.cold + (size_t)blockIdx.x * kPool * 4;
     const float4* __restrict__ recs = (ACCEL == 1) ? sc.prims_bvh : sc.prims_flat;
-    uint32_t* const stack = s_stack + tid;
+    const ShortStack stack{s_stack + tid, pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow, kShortStack, kThreads};
 
-    for (int i = tid; i < kQueues * kPool; i += kBlock) (&L.items[0][0])[i] = kEmpty;
+    for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
     if (tid < kQueues) { L.count[tid] = 0; L.head[tid] = 0; L.tail[tid] = 0; }
-    if (tid == 0) { L.live = kPool; L.abort = 0; }
+    if (tid == 0) { L.live = kPool; L.abort = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
-    for (int g = 0; g < kPool / kBlock; ++g) take_pixels(L, fa, pp, slot_base, true, (uint32_t)(wave * (kPool / 4) + g * 64 + lane));
+    for (int g = 0; g * 64 < kPool / kWaves; ++g)
+        take_pixels(L, fa, cold_base, g * 64 + lane < kPool / kWaves, (uint32_t)(wave * (kPool / kWaves) + g * 64 + lane));
 
     // the ray this lane walks the BVH for
-    int slot = -1;   // local slot index, -1: none
+    int slot = -1;   // slot index, -1: none
     int skind = 0;   // queue its result goes to
     V3 ro = v3(0.0f), rd = v3(0.0f, 0.0f, 1.0f);
     Slab sl = make_slab(ro, rd);
     Trav tv;
     trav_reset(tv, kTravDone);
+    float t_occl = -kInf;  // a light query ends at the first hit nearer than this
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, guard = 0;
     unsigned long long wave_iters = 0;
+    unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
+    unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
 
     for (;;) {
         if (lds_peek(&L.abort) != 0u) break;
@@ -178,27 +264,33 @@ __global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, c
         if (c_next > best) { best = c_next; q = Q_NEXT; }
         if (c_first > best) { best = c_first; q = Q_FIRST; }
         if (c_end > best) { best = c_end; q = Q_END; }
-        const unsigned long long busy = __ballot(tv.cur != kTravDone || slot >= 0);
+        const unsigned long long busy = __ballot(slot >= 0);
         const bool nothing_to_search = (busy == 0ull) && lds_peek(&L.count[Q_SEARCH]) == 0u;
-        if (best >= 64u || (nothing_to_search && best != 0u)) {
+        if (best >= (uint32_t)job_min || (nothing_to_search && best != 0u)) {
             uint32_t item = 0;
             bool got;
-            if (queue_pop(L, q, ~0ull, item, got) == 0u) continue;
+            const uint32_t n_items = queue_pop(L, q, ~0ull, best >= (uint32_t)job_min ? (uint32_t)job_min : 1u, item, got);
+            if (n_items == 0u) continue;
             guard = 0;
+            if (STATS) job_stats[q - Q_FIRST] += ((unsigned long long)n_items << 32) | 1ull;
+            const uint32_t i = item & 0xfffu;
+            const PoolSlot ps{L, cold_base + 4 * i, i};
             if (q == Q_END) {
                 bool alive = false;
-                if (got) end_item(fa, pp, slot_base + item, alive);
-                queue_push(L, Q_SEARCH, got && alive, item);  // WF_PATH_FIRST
-                take_pixels(L, fa, pp, slot_base, got && !alive, item);
+                if (got) end_item(fa, ps, alive);
+                queue_push(L, Q_SEARCH, got && alive, i);  // WF_PATH_FIRST
+                take_pixels(L, fa, cold_base, got && !alive, i);
             } else {
                 bool ends = false;
                 uint32_t next_stage = WF_IDLE;
-                if (got) ends = shade_item(sc, fa, pp, recs, q - Q_FIRST, slot_base + item, next_stage);
+                if (got) ends = shade_item(sc, fa, ps, recs, q - Q_FIRST, WF_LIGHT_SEARCH + (item >> 12), next_stage);
                 const bool go = got && !ends;
-                queue_push(L, Q_END, got && ends, item);
-                queue_push(L, Q_SEARCH, go && next_stage == WF_PATH_NEXT, item | (1u << 12));
-                queue_push(L, Q_SEARCH, go && next_stage == WF_LIGHT_SEARCH, item | (2u << 12));
-                queue_push(L, Q_LIGHT, go && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF, item);
+                queue_push(L, Q_END, got && ends, i);
+                queue_push(L, Q_SEARCH, go && next_stage == WF_PATH_NEXT, i | (1u << 12));
+                queue_push(L, Q_SEARCH, go && next_stage == WF_LIGHT_SEARCH, i | (2u << 12));
+                // light picked without a search: straight to the light-result stage, the case in the entry
+                queue_push(L, Q_LIGHT, go && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF,
+                           i | ((next_stage - WF_LIGHT_SEARCH) << 12));
             }
             continue;
         }
@@ -207,26 +299,33 @@ __global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, c
         const unsigned long long ended = __ballot(tv.cur == kTravDone && slot >= 0);
         if (ended != 0ull) {
             const bool mine = (tv.cur == kTravDone && slot >= 0);
-            if (mine) pp.hit[slot_base + (uint32_t)slot] = make_uint2(__float_as_uint(tv.best_t), (uint32_t)tv.best_idx);
+            if (mine) {
+                L.hit_t[slot] = tv.best_t;
+                L.hit_idx[slot] = tv.best_idx;
+            }
             queue_push(L, Q_FIRST, mine && skind == 0, (uint32_t)slot);
             queue_push(L, Q_NEXT, mine && skind == 1, (uint32_t)slot);
-            queue_push(L, Q_LIGHT, mine && skind == 2, (uint32_t)slot);
+            queue_push(L, Q_LIGHT, mine && skind == 2, (uint32_t)slot);  // entry kind bits 0 = searched
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
         if (idle != 0ull && (__popcll(idle) >= refill_min || idle == ~0ull)) {
             uint32_t item = 0;
             bool got;
-            if (queue_pop(L, Q_SEARCH, idle, item, got) != 0u && got) {
+            if (queue_pop(L, Q_SEARCH, idle, 1u, item, got) != 0u && got) {
                 slot = (int)(item & 0xfffu);
                 skind = (int)(item >> 12);
-                const uint32_t s = slot_base + (uint32_t)slot;
-                ro = xyz(pp.ray_o[s]);
-                rd = xyz(pp.ray_d[s]);
+                ro = v3(L.ro[0][slot], L.ro[1][slot], L.ro[2][slot]);
+                rd = v3(L.rd[0][slot], L.rd[1][slot], L.rd[2][slot]);
                 n_rays++;
                 if (ACCEL == 1) {
                     sl = make_slab(ro, rd);
                     trav_reset(tv, 0);  // node 0 is always an internal node
+                    t_occl = -kInf;
+                    if (skind == 2) {
+                        tv.best_t = L.hit_t[slot];
+                        t_occl = __int_as_float(L.hit_idx[slot]);
+                    }
                 } else {
                     trav_reset(tv, kTravDone);
                     trace_flat(sc, ro, rd, tv.best_t, tv.best_idx);
@@ -249,12 +348,15 @@ __global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, c
                 if (STATS) wave_iters++;
                 if (__popcll(m_node) >= __popcll(m_leaf)) {
                     if (tv.cur >= 0 && tv.cur != kTravDone) {
+                        const int sp_before = tv.sp;
                         trav_node_step(sc.nodes, sl, stack, tv);
                         if (STATS) n_nodes++;
+                        if (STATS && tv.sp > sp_before) deep_pushes += (sp_before >= 4 ? (1ull << 32) : 0ull) + (sp_before >= 8 ? 1ull : 0ull) + (sp_before >= 6 ? (1ull << 16) : 0ull);
                     }
                 } else {
                     if (tv.cur < 0) {
                         trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
+                        if (tv.best_t < t_occl) tv.cur = kTravDone;
                         if (STATS) n_tests++;
                     }
                 }
@@ -264,7 +366,9 @@ __global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, c
 
     // ---- counters: one atomic per wave
     unsigned long long r = n_rays, nn = n_nodes, nt = n_tests;
+    unsigned long long dp4 = deep_pushes >> 32, dp6 = (deep_pushes >> 16) & 0xffffu, dp8 = deep_pushes & 0xffffu;
     for (int off = 32; off > 0; off >>= 1) {
+        if (STATS) { dp4 += __shfl_down(dp4, off); dp6 += __shfl_down(dp6, off); dp8 += __shfl_down(dp8, off); }
         r += __shfl_down(r, off);
         if (STATS) {
             nn += __shfl_down(nn, off);
@@ -279,23 +383,31 @@ __global__ void __launch_bounds__(kBlock, 4) pool_kernel(const DeviceScene sc, c
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);
             atomicAdd((unsigned long long*)(fa.counters + 16), nn + (ACCEL == 1 ? nt : 0ull));
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
+            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), job_stats[k]);
+            atomicAdd((unsigned long long*)(fa.counters + 28), (dp4 << 40) | (dp6 << 20) | dp8);
         }
         if (lds_peek(&L.abort) != 0u) atomicExch(&fa.counters[30], 1u);
     }
 }
 
+typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int);
+PoolKernel pick_kernel(int accel, bool stats) {
+    return accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
+}
+constexpr size_t kStackLds = (size_t)kShortStack * kThreads * sizeof(uint32_t);
+
 }  // namespace
 
 int pool_slots_per_block() { return kPool; }
+int pool_threads_per_block() { return kThreads; }
+int pool_overflow_per_lane() { return kOverflow; }
 
 // Workgroups of the pooled launch: as many as are resident at once, fewer when the image
-// is small.  The path pool must hold grid * pool_slots_per_block() slots.
+// is small.  The path pool must hold grid * pool_slots_per_block() cold records and
+// grid * pool_threads_per_block() * pool_overflow_per_lane() stack words.
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, unsigned* grid) {
-    void (*kernel)(DeviceScene, FrameArgs, PathPool, int, int) =
-        accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
-    const size_t lds = (size_t)fa.stack_depth * kBlock * sizeof(uint32_t);
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(accel, stats), kThreads, kStackLds);
     if (e != hipSuccess) return e;
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     if (const char* q = getenv("RT_POOL_PER_CU")) {  // tuning aid
@@ -308,12 +420,9 @@ hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, u
 }
 
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, hipStream_t stream) {
+                       int refill_min, int burst, int job_min, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
-    void (*kernel)(DeviceScene, FrameArgs, PathPool, int, int) =
-        accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
-    const size_t lds = (size_t)fa.stack_depth * kBlock * sizeof(uint32_t);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, sc, fa, pp, refill_min, burst);
+    hipLaunchKernelGGL(pick_kernel(accel, stats), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min);
     return hipGetLastError();
 }
 

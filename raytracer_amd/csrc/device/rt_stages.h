@@ -1,6 +1,7 @@
 // rt_stages.h — the per-path pieces of the shader's program between two nearest-hit
-// searches, operating on one slot of path state in device memory (PathPool).  Shared by the
-// staged pipeline (rt_wavefront.hip) and the pooled pipeline (rt_pool.hip).
+// searches, written against an accessor of one slot of path state, so that the staged
+// pipeline (state in device memory, rt_wavefront.hip) and the pooled pipeline (hot state in
+// LDS, rt_pool.hip) run the very same arithmetic.
 #pragma once
 #include "rt_trace.h"
 
@@ -11,20 +12,66 @@ RT_DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
 RT_DEV V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
 RT_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
+// What a slot keeps across a light query besides the query ray itself (whose origin is the
+// shading point): normal, material and facing of the shading point, the direction of the
+// path ray that reached it, the distance to the sampled light point and the light's index.
+struct LightQuery {
+    V3 normal;
+    V3 vdir;
+    int mat;
+    bool front_face;
+    float s_d;
+    int light;
+};
+
+// Accessor of slot `s` of a PathPool in device memory.
+struct GlobalSlot {
+    const PathPool& pp;
+    uint32_t s;
+    RT_DEV void get_ctl(uint32_t& seed, uint32_t& pixel, uint32_t& sample, int& bounce) const {
+        const uint4 c = pp.ctl[s];
+        seed = c.x; pixel = c.y; sample = c.z; bounce = (int)c.w;
+    }
+    RT_DEV void put_ctl(uint32_t seed, uint32_t pixel, uint32_t sample, int bounce) const { pp.ctl[s] = make_uint4(seed, pixel, sample, (uint32_t)bounce); }
+    RT_DEV V3 get_att(uint32_t& phash) const { const float4 a = pp.att[s]; phash = __float_as_uint(a.w); return xyz(a); }
+    RT_DEV void put_att(V3 a, uint32_t phash) const { pp.att[s] = f4(a, __uint_as_float(phash)); }
+    RT_DEV V3 get_ro() const { return xyz(pp.ray_o[s]); }
+    RT_DEV V3 get_rd() const { return xyz(pp.ray_d[s]); }
+    RT_DEV void put_ro(V3 v) const { pp.ray_o[s] = f4(v, 0.0f); }
+    RT_DEV void put_rd(V3 v) const { pp.ray_d[s] = f4(v, 0.0f); }
+    RT_DEV void get_hit(float& t, int& idx) const { const uint2 r = pp.hit[s]; t = __uint_as_float(r.x); idx = (int)r.y; }
+    RT_DEV V3 get_col() const { return xyz(pp.col[s]); }
+    RT_DEV void put_col(V3 v) const { pp.col[s] = f4(v, 0.0f); }
+    RT_DEV V3 get_pix() const { return xyz(pp.pix[s]); }
+    RT_DEV void put_pix(V3 v) const { pp.pix[s] = f4(v, 0.0f); }
+    RT_DEV void put_stage(uint32_t st) const { pp.stage[s] = st; }
+    RT_DEV void put_search_bounds(float, float) const {}  // the staged search always finds the true nearest hit
+    RT_DEV void put_light_query(const LightQuery& q) const {
+        pp.hn[s] = f4(q.normal, q.s_d);
+        pp.vdir[s] = f4(q.vdir, __uint_as_float((uint32_t)q.light));
+        pp.hp[s] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)q.mat | (q.front_face ? 0x80000000u : 0u)));
+    }
+    RT_DEV void get_light_query(LightQuery& q) const {
+        const float4 n = pp.hn[s], v = pp.vdir[s];
+        const uint32_t mbits = __float_as_uint(pp.hp[s].w);
+        q.normal = xyz(n); q.s_d = n.w;
+        q.vdir = xyz(v); q.light = (int)__float_as_uint(v.w);
+        q.mat = (int)(mbits & 0x7fffffffu); q.front_face = (mbits >> 31) != 0u;
+    }
+};
+
 // A path result (kind 0: bounce 0, kind 1: later bounces; raytracer.comp:891-921) or a
-// light-query result (kind 2; raytracer.comp:617-671, 870-881) for slot s, followed for
-// the lanes that reach it by the bounce itself: sample_mat + eval_mat (raytracer.comp:913-921).
-// Returns true when the sample ends here (end_item follows); otherwise next_stage is what the
-// slot waits for now.
-RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, const float4* __restrict__ recs, int kind,
-                       uint32_t s, uint32_t& next_stage) {
-    const uint4 c = pp.ctl[s];
-    uint32_t seed = c.x;
-    const uint32_t pixel = c.y;
-    int bounce = (int)c.w;
-    const float4 a4 = pp.att[s];
-    V3 att = xyz(a4);
-    uint32_t phash = __float_as_uint(a4.w);
+// light-query result (kind 2, `stage` = which of the WF_LIGHT_* cases; raytracer.comp:617-671,
+// 870-881), followed for the lanes that reach it by the bounce itself: sample_mat + eval_mat
+// (raytracer.comp:913-921).  Returns true when the sample ends here (end_item follows);
+// otherwise next_stage is what the slot waits for now.
+template <typename Slot>
+RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& sl, const float4* __restrict__ recs, int kind,
+                       uint32_t stage, uint32_t& next_stage) {
+    uint32_t seed, pixel, sample, phash;
+    int bounce;
+    sl.get_ctl(seed, pixel, sample, bounce);
+    V3 att = sl.get_att(phash);
     bool do_bsdf = false, to_end = false;
     next_stage = WF_IDLE;
     Hit h;
@@ -33,79 +80,93 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const PathPoo
     Material mat;
 
     if (kind == 2) {
-        const uint32_t st = pp.stage[s];
-        const float4 o4 = pp.ray_o[s];   // w: distance to the sampled light point
-        const float4 d4 = pp.ray_d[s];   // xyz: direction to it; w: light index
-        const float4 p4 = pp.hp[s];
-        const uint32_t mbits = __float_as_uint(p4.w);
-        h.p = xyz(p4);
-        h.mat = (int)(mbits & 0x7fffffffu);
-        h.front_face = (mbits >> 31) != 0u;
-        h.normal = xyz(pp.hn[s]);
-        V = -xyz(pp.vdir[s]);
-        const int light = (int)__float_as_uint(d4.w);
-        const float4 lc = sc.lights[3 * light + 1];
-        const int ltype = __float_as_int(sc.lights[3 * light + 2].x);
+        LightQuery q;
+        sl.get_light_query(q);
+        h.p = sl.get_ro();
+        const V3 s_L = sl.get_rd();
+        h.mat = q.mat;
+        h.front_face = q.front_face;
+        h.normal = q.normal;
+        V = -q.vdir;
+        const float4 lc = sc.lights[3 * q.light + 1];
+        const int ltype = __float_as_int(sc.lights[3 * q.light + 2].x);
         V3 Le = v3(0.0f), Ldir = v3(0.0f);
         float light_pdf = 0.0f;
-        if (st == WF_LIGHT_SEARCH) {
-            const uint2 r = pp.hit[s];
-            const int hit_idx = (int)r.y;
+        if (stage == WF_LIGHT_SEARCH) {
+            float hit_t;
+            int hit_idx;
+            sl.get_hit(hit_t, hit_idx);
             const int prim_id = (hit_idx >= 0) ? __float_as_int(recs[3 * hit_idx].w) : -1;
             phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
-            light_arrival(ltype, lc, hit_idx, __uint_as_float(r.x), o4.w, xyz(d4), h.normal, Le, Ldir, light_pdf);
-        } else if (st == WF_LIGHT_AMBIENT) {
-            Ldir = xyz(d4);
+            light_arrival(ltype, lc, hit_idx, hit_t, q.s_d, s_L, h.normal, Le, Ldir, light_pdf);
+        } else if (stage == WF_LIGHT_AMBIENT) {
+            Ldir = s_L;
             light_pdf = 1.0f / 2.0f / kPi;
             Le = v3(lc.x, lc.y, lc.z);
-        } else if (st == WF_LIGHT_UNDEF) {
+        } else if (stage == WF_LIGHT_UNDEF) {
             Le = v3(1.0f);
         }
         mat = load_material(sc.materials, h.mat);
         if (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f) {
             // the first thing a sample adds to its radiance (raytracer.comp:907-910)
-            V3 col = v3(0.0f) + direct_term(mat, h, V, Le, Ldir, light_pdf, att);
-            pp.col[s] = f4(col, 0.0f);
+            sl.put_col(v3(0.0f) + direct_term(mat, h, V, Le, Ldir, light_pdf, att));
         }
         do_bsdf = true;
     } else {
-        const V3 ro = xyz(pp.ray_o[s]);
-        const V3 rd = xyz(pp.ray_d[s]);
-        const uint2 r = pp.hit[s];
-        const int hit_idx = (int)r.y;
+        const V3 ro = sl.get_ro();
+        const V3 rd = sl.get_rd();
+        float hit_t;
+        int hit_idx;
+        sl.get_hit(hit_t, hit_idx);
         int prim_id = -1;
         if (hit_idx < 0) {
-            V3 col = xyz(pp.col[s]) + att * v3(0.3f);  // skybox_color_grey, raytracer.comp:570-577, 924
-            pp.col[s] = f4(col, 0.0f);
+            sl.put_col(sl.get_col() + att * v3(0.3f));  // skybox_color_grey, raytracer.comp:570-577, 924
             to_end = true;
         } else {
-            make_hit(sc, recs, hit_idx, __uint_as_float(r.x), ro, rd, h, prim_id);
+            make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);
             mat = load_material(sc.materials, h.mat);
             if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
-                pp.ray_o[s] = f4(h.p, 0.0f);
+                sl.put_ro(h.p);
                 bounce++;
                 if (bounce > fa.max_bounces) to_end = true; else next_stage = WF_PATH_NEXT;
             } else if (mat.emission_a > 0.0f) {  // raytracer.comp:901-904
-                V3 col = xyz(pp.col[s]) + att * mat.emission;
-                pp.col[s] = f4(col, 0.0f);
+                sl.put_col(sl.get_col() + att * mat.emission);
                 to_end = true;
             } else if (kind == 0 && !(fa.total_lights == 0 || fa.lights_strength_sum <= 0.0f)) {
-                int light;
+                LightQuery q;
                 V3 s_L;
-                float s_d;
-                const int q = light_pick(sc, fa, h, seed, light, s_L, s_d);
-                pp.hp[s] = f4(h.p, __uint_as_float((uint32_t)h.mat | (h.front_face ? 0x80000000u : 0u)));
-                pp.hn[s] = f4(h.normal, 0.0f);
-                pp.vdir[s] = f4(rd, 0.0f);
-                pp.ray_o[s] = f4(h.p, s_d);
-                pp.ray_d[s] = f4(s_L, __uint_as_float((uint32_t)light));
-                next_stage = WF_LIGHT_SEARCH + (uint32_t)q;
+                const int k = light_pick(sc, fa, h, seed, q.light, s_L, q.s_d);
+                q.normal = h.normal;
+                q.vdir = rd;
+                q.mat = h.mat;
+                q.front_face = h.front_face;
+                sl.put_light_query(q);
+                sl.put_ro(h.p);
+                sl.put_rd(s_L);
+                if (k == 0) {
+                    // A light-visibility query only asks whether the nearest hit lies within 0.1 of the
+                    // sampled point's distance s_d (raytracer.comp:617-626, 662-671), or, for a directional
+                    // light, whether anything is hit at all (636-644): its search may be bounded to
+                    // t < s_d + 0.2 and end at the first hit nearer than s_d - 0.2.  Not when the per-pixel
+                    // hash of nearest-hit ids is recorded, which needs the true nearest hit.
+                    float t_max = kInf, t_occl = -kInf;
+                    if (!(fa.flags & 2u)) {
+                        if (__float_as_int(sc.lights[3 * q.light + 2].x) == 3 /* DIRECTIONAL */) {
+                            t_occl = kInf;
+                        } else {
+                            t_max = q.s_d + 0.2f;
+                            t_occl = q.s_d - 0.2f;
+                        }
+                    }
+                    sl.put_search_bounds(t_max, t_occl);
+                }
+                next_stage = WF_LIGHT_SEARCH + (uint32_t)k;
             } else {
                 V = -rd;
                 do_bsdf = true;
             }
         }
-        if (kind == 0 && c.z == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel] = prim_id;
+        if (kind == 0 && sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel] = prim_id;
         phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
     }
 
@@ -115,38 +176,44 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const PathPoo
         V3 fr = eval_mat(mat, bounce_dir, V, h, mat_pdf);
         float cos_theta = g_abs(dot(h.normal, bounce_dir));
         att = att * g_max(v3(0.0f), fr * cos_theta / g_max(0.00001f, mat_pdf));
-        pp.ray_o[s] = f4(h.p, 0.0f);
-        pp.ray_d[s] = f4(bounce_dir, 0.0f);
+        sl.put_ro(h.p);
+        sl.put_rd(bounce_dir);
         bounce++;
         if (bounce > fa.max_bounces) to_end = true; else next_stage = WF_PATH_NEXT;
     }
-    pp.ctl[s] = make_uint4(seed, pixel, c.z, (uint32_t)bounce);
-    pp.att[s] = f4(att, __uint_as_float(phash));
-    if (!to_end) pp.stage[s] = next_stage;
+    sl.put_ctl(seed, pixel, sample, bounce);
+    sl.put_att(att, phash);
+    if (!to_end) sl.put_stage(next_stage);
     return to_end;
 }
 
-// End of a sample (raytracer.comp:925/929, 974) and either the next sample's primary ray
-// (get_ray, raytracer.comp:933-952) or the pixel's gamma, accumulation and rgba8 store
-// (raytracer.comp:978-995).
-RT_DEV void end_item(const FrameArgs& fa, const PathPool& pp, uint32_t s, bool& alive) {
-    const uint4 c = pp.ctl[s];
-    uint32_t seed = c.x;
-    const uint32_t pixel = c.y;
-    const int sample = (int)c.z + 1;
-    V3 pix = xyz(pp.pix[s]) + g_clamp(xyz(pp.col[s]), 0.0f, 1.0f);
-    const float phash_bits = pp.att[s].w;
-    if (sample < fa.spp) {
-        const int px = (int)(pixel % (uint32_t)fa.width), py = (int)(pixel / (uint32_t)fa.width);
-        V3 ro, rd;
-        generate_ray(fa, px, py, seed, ro, rd);
-        pp.ctl[s] = make_uint4(seed, pixel, (uint32_t)sample, 0u);
-        pp.ray_o[s] = f4(ro, 0.0f);
-        pp.ray_d[s] = f4(rd, 0.0f);
-        pp.att[s] = make_float4(1.0f, 1.0f, 1.0f, phash_bits);
-        pp.col[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        pp.pix[s] = f4(pix, 0.0f);
-        pp.stage[s] = WF_PATH_FIRST;
+// First primary ray of a sample (get_ray, raytracer.comp:933-952) into the slot.
+template <typename Slot>
+RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t phash) {
+    const int px = (int)(pixel % (uint32_t)fa.width), py = (int)(pixel / (uint32_t)fa.width);
+    V3 ro, rd;
+    generate_ray(fa, px, py, seed, ro, rd);
+    sl.put_ctl(seed, pixel, sample, 0);
+    sl.put_ro(ro);
+    sl.put_rd(rd);
+    sl.put_att(v3(1.0f), phash);
+    sl.put_col(v3(0.0f));
+    sl.put_stage(WF_PATH_FIRST);
+}
+
+// End of a sample (raytracer.comp:925/929, 974) and either the next sample's primary ray or
+// the pixel's gamma, accumulation and rgba8 store (raytracer.comp:978-995).
+template <typename Slot>
+RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
+    uint32_t seed, pixel, sample, phash;
+    int bounce;
+    sl.get_ctl(seed, pixel, sample, bounce);
+    sample += 1u;
+    V3 pix = sl.get_pix() + g_clamp(sl.get_col(), 0.0f, 1.0f);
+    (void)sl.get_att(phash);
+    if ((int)sample < fa.spp) {
+        sl.put_pix(pix);
+        start_sample(fa, sl, seed, pixel, sample, phash);
         alive = true;
     } else {
         V3 cc = g_pow(pix / (float)fa.spp, 1.0f / 2.2f);
@@ -161,10 +228,18 @@ RT_DEV void end_item(const FrameArgs& fa, const PathPool& pp, uint32_t s, bool& 
         fa.accum[pixel] = a;
         fa.counts[pixel] = n;
         fa.bgra[pixel] = resolve_pixel(a, n);
-        if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[pixel] = __float_as_uint(phash_bits);
-        pp.stage[s] = WF_IDLE;
+        if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[pixel] = phash;
+        sl.put_stage(WF_IDLE);
         alive = false;
     }
+}
+
+// A slot's first sample of pixel (x, y): seed (raytracer.comp:959-961), empty pixel sum.
+template <typename Slot>
+RT_DEV void start_pixel(const FrameArgs& fa, const Slot& sl, int x, int y) {
+    const uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
+    sl.put_pix(v3(0.0f));
+    start_sample(fa, sl, seed, (uint32_t)(y * fa.width + x), 0u, 0u);
 }
 
 }  // namespace rtd

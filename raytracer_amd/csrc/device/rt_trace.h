@@ -82,12 +82,33 @@ RT_DEV void trav_reset(Trav& tv, int cur) {
     tv.best_idx = -1;
 }
 
-RT_DEV void trav_pop(Trav& tv, const uint32_t* __restrict__ stack) {
+// Per-lane traversal stack.  LdsStack: column of a [depth][block] LDS array (bank = tid mod
+// 32 at every depth, so conflict-free).  ShortStack: the same for the first `depth` entries,
+// deeper entries in a lane-private overflow area in device memory (rarely reached: an entry
+// is pushed only where the ray enters both children).
+struct LdsStack {
+    uint32_t* base;
+    RT_DEV void put(int sp, uint32_t v) const { base[sp * kBlock] = v; }
+    RT_DEV uint32_t get(int sp) const { return base[sp * kBlock]; }
+};
+struct ShortStack {
+    uint32_t* base;
+    uint32_t* overflow;
+    int depth;
+    int stride;  // threads per workgroup
+    RT_DEV void put(int sp, uint32_t v) const {
+        if (sp < depth) base[sp * stride] = v; else overflow[sp - depth] = v;
+    }
+    RT_DEV uint32_t get(int sp) const { return (sp < depth) ? base[sp * stride] : overflow[sp - depth]; }
+};
+
+template <typename Stack>
+RT_DEV void trav_pop(Trav& tv, const Stack& stack) {
     if (tv.sp == 0) {
         tv.cur = kTravDone;
     } else {
         tv.sp--;
-        tv.cur = (int)stack[tv.sp * kBlock];
+        tv.cur = (int)stack.get(tv.sp);
     }
 }
 
@@ -114,9 +135,9 @@ RT_DEV Slab make_slab(V3 ro, V3 rd) {
 }
 
 // Visit the internal node under the cursor: slab-test both children, descend into the
-// nearer hit child, push the other (per-lane stack: column of a [depth][block] LDS array,
-// bank = tid mod 32 at every depth, so conflict-free).
-RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, uint32_t* __restrict__ stack, Trav& tv) {
+// nearer hit child, push the other.
+template <typename Stack>
+RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
     const float4 q0 = nodes[4 * tv.cur + 0];
     const float4 q1 = nodes[4 * tv.cur + 1];
     const float4 q2 = nodes[4 * tv.cur + 2];
@@ -140,7 +161,7 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, uin
     int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
     if (hit0 && hit1) {
         if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
-        stack[tv.sp * kBlock] = (uint32_t)r1;
+        stack.put(tv.sp, (uint32_t)r1);
         tv.sp++;
         tv.cur = r0;
     } else if (hit0) {
@@ -153,7 +174,8 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, uin
 }
 
 // Test the next primitive of the leaf under the cursor.
-RT_DEV void trav_leaf_step(const float4* __restrict__ prims, V3 ro, V3 rd, const uint32_t* __restrict__ stack, Trav& tv) {
+template <typename Stack>
+RT_DEV void trav_leaf_step(const float4* __restrict__ prims, V3 ro, V3 rd, const Stack& stack, Trav& tv) {
     const int first = tv.cur & 0x0fffffff;
     const int left = (tv.cur >> 28) & 7;  // primitives after this one
     intersect_record(prims, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);

@@ -40,16 +40,8 @@ __global__ void __launch_bounds__(kBlock) wf_generate_kernel(const FrameArgs fa,
     int x, y;
     uint32_t st = WF_IDLE;
     if (slot_to_pixel(fa, s, x, y)) {
-        uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
-        V3 ro, rd;
-        generate_ray(fa, x, y, seed, ro, rd);
-        pp.ctl[s] = make_uint4(seed, (uint32_t)(y * fa.width + x), 0u, 0u);
-        pp.ray_o[s] = f4(ro, 0.0f);
-        pp.ray_d[s] = f4(rd, 0.0f);
-        pp.att[s] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        pp.col[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        pp.pix[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        st = WF_PATH_FIRST;
+        start_pixel(fa, GlobalSlot{pp, s}, x, y);
+        return;
     }
     pp.stage[s] = st;
 }
@@ -67,7 +59,7 @@ __global__ void __launch_bounds__(kBlock) wf_search_kernel(const DeviceScene sc,
     if (iter > 0 && pp.active[iter] == 0u) return;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    uint32_t* const stack = s_mem + tid;
+    const LdsStack stack{s_mem + tid};
     uint32_t* const list = s_mem + (size_t)fa.stack_depth * kBlock + (tid & ~63);
 
     const uint32_t n_groups = (pp.n_slots + 63u) / 64u;
@@ -230,7 +222,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_shade_kernel(const DeviceScene s
                 if (valid) {
                     uint32_t next_stage;
                     o = L.list[kind][idx];
-                    ends = shade_item(sc, fa, pp, recs, kind, base + o, next_stage);
+                    ends = shade_item(sc, fa, GlobalSlot{pp, base + o}, recs, kind, pp.stage[base + o], next_stage);
                     alive = !ends;
                 }
                 list_push(L, 3, ends, o);
@@ -249,7 +241,7 @@ __global__ void __launch_bounds__(kBlock, 4) wf_shade_kernel(const DeviceScene s
                 if (chunk >= c3) break;
                 const uint32_t idx = chunk * 64u + (uint32_t)lane;
                 bool alive = false;
-                if (idx < n3) end_item(fa, pp, base + L.list[3][idx], alive);
+                if (idx < n3) end_item(fa, GlobalSlot{pp, base + L.list[3][idx]}, alive);
                 count_lanes(&L.alive, alive);
             }
         }

@@ -46,7 +46,7 @@ struct RtContext {
 
     // path state of the staged pipeline (allocated on first use, grown when needed)
     void* d_pool = nullptr;
-    size_t pool_slots = 0;
+    size_t pool_bytes = 0;
     uint32_t* d_active = nullptr;
     size_t active_len = 0;
 
@@ -107,25 +107,30 @@ void free_pool(RtContext* c) {
     if (c->d_active) (void)hipFree(c->d_active);
     c->d_pool = nullptr;
     c->d_active = nullptr;
-    c->pool_slots = 0;
+    c->pool_bytes = 0;
     c->active_len = 0;
 }
 
-// Bytes of path state per slot: stage word, ctl, hit, and nine float4 arrays.
-constexpr size_t kPoolBytesPerSlot = 4 + 16 + 8 + 9 * 16;
-
-// One allocation carved into the PathPool arrays (16-byte arrays first, so every array is
-// aligned for its widest load).
-int ensure_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& pp) {
-    if (n_slots > c->pool_slots) {
+// Device memory of the staged / pooled pipelines: one allocation, grown when needed.
+int ensure_pool_bytes(RtContext* c, size_t bytes) {
+    if (bytes > c->pool_bytes) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
         if (c->d_pool) (void)hipFree(c->d_pool);
         c->d_pool = nullptr;
-        c->pool_slots = 0;
-        size_t cap = (n_slots + 255) / 256 * 256;
-        RT_HIP(c, hipMalloc(&c->d_pool, cap * kPoolBytesPerSlot));
-        c->pool_slots = cap;
+        c->pool_bytes = 0;
+        size_t cap = (bytes + 4095) / 4096 * 4096;
+        RT_HIP(c, hipMalloc(&c->d_pool, cap));
+        c->pool_bytes = cap;
     }
+    return RT_OK;
+}
+
+// Staged pipeline: 156 B of path state per slot (stage word, ctl, hit, nine float4 arrays),
+// carved out of the allocation 16-byte arrays first, plus the per-iteration live counters.
+int ensure_staged_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& pp) {
+    const size_t cap = (n_slots + 255) / 256 * 256;
+    int rc = ensure_pool_bytes(c, cap * (4 + 16 + 8 + 9 * 16));
+    if (rc != RT_OK) return rc;
     if (iterations + 2 > c->active_len) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
         if (c->d_active) (void)hipFree(c->d_active);
@@ -135,7 +140,6 @@ int ensure_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& 
         RT_HIP(c, hipMalloc((void**)&c->d_active, len * 4));
         c->active_len = len;
     }
-    const size_t cap = c->pool_slots;
     char* p = (char*)c->d_pool;
     auto take = [&](size_t bytes_per_slot) { char* r = p; p += cap * bytes_per_slot; return (void*)r; };
     pp.ctl = (uint4*)take(16);
@@ -151,6 +155,21 @@ int ensure_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& 
     pp.stage = (uint32_t*)take(4);
     pp.active = c->d_active;
     pp.n_slots = (uint32_t)n_slots;
+    pp.cold = nullptr;
+    pp.stack_overflow = nullptr;
+    return RT_OK;
+}
+
+// Pooled pipeline: per workgroup 64 B of cold state per slot and a stack overflow area per lane.
+int ensure_pooled_pool(RtContext* c, unsigned grid, rtd::PathPool& pp) {
+    memset(&pp, 0, sizeof pp);
+    const size_t cold = (size_t)grid * (size_t)rtd::pool_slots_per_block() * 64;
+    const size_t ovf = (size_t)grid * (size_t)rtd::pool_threads_per_block() * (size_t)rtd::pool_overflow_per_lane() * 4;
+    int rc = ensure_pool_bytes(c, cold + ovf);
+    if (rc != RT_OK) return rc;
+    pp.cold = (float4*)c->d_pool;
+    pp.stack_overflow = (uint32_t*)((char*)c->d_pool + cold);
+    pp.n_slots = grid * (unsigned)rtd::pool_slots_per_block();
     return RT_OK;
 }
 
@@ -420,23 +439,30 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (p.flags & RT_FLAG_POOLED) {
             unsigned grid = 0;
             RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
+            if (p.spp > 65535 || p.max_bounces > 65534)
+                return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline packs sample and bounce counters into 16 bits each");
             rtd::PathPool pp;
-            int rc = ensure_pool(c, (size_t)grid * (size_t)rtd::pool_slots_per_block(), 0, pp);
+            int rc = ensure_pooled_pool(c, grid, pp);
             if (rc != RT_OK) return rc;
-            int burst = 8;
+            int burst = 16;
             if (const char* q = getenv("RT_POOL_BURST")) {  // tuning aid
                 int v = atoi(q);
                 if (v >= 1 && v <= 1024) burst = v;
             }
+            int job_min = 64;
+            if (const char* q = getenv("RT_POOL_JOB_MIN")) {  // tuning aid
+                int v = atoi(q);
+                if (v >= 1 && v <= 64) job_min = v;
+            }
             RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
-            RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, refill_min, burst, c->stream));
+            RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, refill_min, burst, job_min, c->stream));
         } else if (p.flags & RT_FLAG_WAVEFRONT) {
             // every live path advances by one ray per iteration; a sample needs at most
             // max_bounces + 1 path rays and one light query
             long long iterations = (long long)p.spp * ((long long)p.max_bounces + 2);
             if (iterations > (1ll << 20)) return fail(c, RT_ERR_TOO_LARGE, "spp x (max_bounces + 2) exceeds 2^20 launches pairs");
             rtd::PathPool pp;
-            int rc = ensure_pool(c, fa.total_slots, (size_t)iterations, pp);
+            int rc = ensure_staged_pool(c, fa.total_slots, (size_t)iterations, pp);
             if (rc != RT_OK) return rc;
             RT_HIP(c, hipMemsetAsync(c->d_active, 0, ((size_t)iterations + 2) * 4, c->stream));
             RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));

@@ -20,3 +20,8 @@ for f in range(n):
     st = ctx.stats()
     print(f"frame {f}: {st.kernel_ms:.3f} ms rays {st.rays} nodes/ray {st.nodes_visited/max(1,st.rays):.2f} tests/ray {st.prims_tested/max(1,st.rays):.2f} "
           f"occupancy {st.lane_iterations/(64*max(1,st.wave_iterations)):.3f}", flush=True)
+    if mode == "pooled" and (flags & capi.RT_FLAG_TRAVERSAL_STATS):
+        names = ["first-bounce", "later-bounce", "light-result", "sample-end"]
+        dp = list(st.cycles_shade_parts)[4]
+        print(f"  pushes at depth >=4: {dp >> 40}, >=6: {(dp >> 20) & 0xfffff}, >=8: {dp & 0xfffff} of {st.nodes_visited} node visits")
+        print("  job fill: " + ", ".join(f"{n} {(v >> 32) / max(1, v & 0xffffffff):.1f}/64 x {v & 0xffffffff}" for n, v in zip(names, list(st.cycles_shade_parts)[:4])), flush=True)
