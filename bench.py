@@ -65,6 +65,9 @@ def main() -> None:
     ap.add_argument("--partition", default=None, choices=["strips", "samples"],
                     help="how N GPUs share the work: row strips of every frame (default) or whole frames "
                          "(sample sharding, default for c4)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled", "staged"],
+                    help="schedule of the per-path program (same results): the library's own choice, the single "
+                         "persistent kernel, the pooled kernel (LDS queues), or one launch per stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
@@ -100,7 +103,9 @@ def main() -> None:
     partition = args.partition or ("samples" if args.workload == "c4" else "strips")
     frames_per_step = FRAMES_PER_BATCH if partition == "samples" else 1
     strip = (STRIP_ROWS, world, rank) if (collective and partition == "strips") else (0, 1, 0)
-    params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], 0)
+    pipe_flags = {"auto": 0, "single": capi.RT_FLAG_SINGLE_KERNEL, "pooled": capi.RT_FLAG_POOLED,
+                  "staged": capi.RT_FLAG_WAVEFRONT}[args.pipeline]
+    params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], pipe_flags)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     main_stream = torch.cuda.current_stream(dev)
     exchange = None
@@ -175,7 +180,8 @@ def main() -> None:
     avg_kernel_ms = float(kern.item())
 
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
-    flags = capi.RT_FLAG_TRAVERSAL_STATS
+    pipeline = ["single", "staged", "pooled"][ctx.stats().pipeline]  # what the timed frames ran on
+    flags = capi.RT_FLAG_TRAVERSAL_STATS | pipe_flags
     pc = scene.push_constants(0.0, args.warmup, False)
     ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
     st = ctx.stats()
@@ -206,7 +212,7 @@ def main() -> None:
         # this workload on one GPU; bench.py cannot run the profiler on itself.
         traffic, traffic_note = None, None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"{args.workload}:{pipeline}")
             if rec and world == 1 and args.accel == "bvh":
                 traffic = (rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024.0
                 traffic_note = rec["note"]
@@ -230,11 +236,11 @@ def main() -> None:
                        "partition": ("single GPU" if not collective else
                                      f"row strips of {STRIP_ROWS} rows, all-gather" if partition == "strips" else
                                      f"frames of a {FRAMES_PER_BATCH}-frame batch dealt to ranks, all-reduce of accumulators"),
-                       "frames_per_step": frames_per_step,
+                       "pipeline": pipeline, "frames_per_step": frames_per_step,
                        "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
             "roofline": {
                 "bound": "valu",
-                "kernel": "render_kernel",
+                "kernel": {"single": "render_kernel", "pooled": "pool_kernel", "staged": "wf_search_kernel + wf_shade_kernel"}[pipeline],
                 "achieved": achieved_tflops,
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",

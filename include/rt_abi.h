@@ -137,9 +137,14 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
        RT_FLAG_WAVEFRONT   = 16u,  /* staged pipeline: one search launch + one shading launch
                                       per ray generation instead of the single persistent kernel;
                                       same results                                              */
-       RT_FLAG_POOLED      = 32u   /* pooled pipeline: one persistent launch whose workgroups keep
-                                      four paths per lane and regroup them by kind of work through
-                                      queues in LDS; same results                                */ };
+       RT_FLAG_POOLED      = 32u,  /* pooled pipeline: one persistent launch whose workgroups keep
+                                      two paths per lane, their hot state in LDS, and regroup them
+                                      by kind of work through queues in LDS; same results         */
+       RT_FLAG_SINGLE_KERNEL = 64u /* the single persistent kernel, one path per lane              */ };
+/* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: the
+ * pooled pipeline when the BVH is used and the frame has at least as many pixels as the pools have
+ * slots (1536 per CU), the single kernel otherwise.  All pipelines give the same bits. */
+enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_STAGED = 1, RT_PIPELINE_POOLED = 2 };
 
 typedef struct RtStats {
     uint64_t rays;          /* nearest-hit searches in the last frame (always counted)         */
@@ -158,6 +163,7 @@ typedef struct RtStats {
     int32_t  bvh_nodes;     /* nodes in the device BVH                                         */
     int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */
     int32_t  total_prims;   /* spheres + triangles + mesh triangles                            */
+    int32_t  pipeline;      /* RT_PIPELINE_* that rendered the last frame                      */
 } RtStats;
 
 typedef struct RtContext RtContext;

@@ -34,6 +34,8 @@ RT_FLAG_COUNT_RAYS = 4
 RT_FLAG_TRAVERSAL_STATS = 8
 RT_FLAG_WAVEFRONT = 16
 RT_FLAG_POOLED = 32
+RT_FLAG_SINGLE_KERNEL = 64
+RT_PIPELINE_SINGLE, RT_PIPELINE_STAGED, RT_PIPELINE_POOLED = 0, 1, 2
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1
@@ -97,7 +99,7 @@ class RtStats(C.Structure):
                 ("cycles_shade", C.c_uint64), ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("cycles_shade_parts", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
-                ("total_prims", C.c_int32)]
+                ("total_prims", C.c_int32), ("pipeline", C.c_int32)]
 
 
 class RtSceneView(C.Structure):

@@ -266,10 +266,14 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (c_end > best) { best = c_end; q = Q_END; }
         const unsigned long long busy = __ballot(slot >= 0);
         const bool nothing_to_search = (busy == 0ull) && lds_peek(&L.count[Q_SEARCH]) == 0u;
-        if (best >= (uint32_t)job_min || (nothing_to_search && best != 0u)) {
+        // a job is worth a wave when it is full; when the pool runs thin (end of the frame, or fewer
+        // pixels than slots) a sixteenth of the live paths must do, or they would wait for each other
+        uint32_t job_thresh = lds_peek(&L.live) >> 4;
+        job_thresh = job_thresh < 1u ? 1u : (job_thresh > (uint32_t)job_min ? (uint32_t)job_min : job_thresh);
+        if (best >= job_thresh || (nothing_to_search && best != 0u)) {
             uint32_t item = 0;
             bool got;
-            const uint32_t n_items = queue_pop(L, q, ~0ull, best >= (uint32_t)job_min ? (uint32_t)job_min : 1u, item, got);
+            const uint32_t n_items = queue_pop(L, q, ~0ull, best >= job_thresh ? job_thresh : 1u, item, got);
             if (n_items == 0u) continue;
             guard = 0;
             if (STATS) job_stats[q - Q_FIRST] += ((unsigned long long)n_items << 32) | 1ull;

@@ -22,6 +22,7 @@ struct RtContext {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
+    int32_t last_pipeline = 0;
 
     // scene
     bool has_scene = false;
@@ -436,10 +437,21 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
             int v = atoi(q);
             if (v >= 1 && v <= 64) refill_min = v;
         }
-        if (p.flags & RT_FLAG_POOLED) {
-            unsigned grid = 0;
+        // which schedule of the per-path program runs this frame (see rt_abi.h)
+        const bool pooled_fits = p.spp <= 65535 && p.max_bounces <= 65534;  // 16-bit sample / bounce counters
+        unsigned grid = 0;
+        int pipeline = RT_PIPELINE_SINGLE;
+        if (p.flags & RT_FLAG_POOLED) pipeline = RT_PIPELINE_POOLED;
+        else if (p.flags & RT_FLAG_WAVEFRONT) pipeline = RT_PIPELINE_STAGED;
+        else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits) {
             RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
-            if (p.spp > 65535 || p.max_bounces > 65534)
+            if ((unsigned long long)fa.total_slots >= (unsigned long long)grid * (unsigned long long)rtd::pool_slots_per_block())
+                pipeline = RT_PIPELINE_POOLED;
+        }
+        c->last_pipeline = pipeline;
+        if (pipeline == RT_PIPELINE_POOLED) {
+            RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
+            if (!pooled_fits)
                 return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline packs sample and bounce counters into 16 bits each");
             rtd::PathPool pp;
             int rc = ensure_pooled_pool(c, grid, pp);
@@ -456,7 +468,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
             }
             RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
             RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, refill_min, burst, job_min, c->stream));
-        } else if (p.flags & RT_FLAG_WAVEFRONT) {
+        } else if (pipeline == RT_PIPELINE_STAGED) {
             // every live path advances by one ray per iteration; a sample needs at most
             // max_bounces + 1 path rays and one light query
             long long iterations = (long long)p.spp * ((long long)p.max_bounces + 2);
@@ -538,6 +550,8 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;
     out->total_prims = c->n_prims;
+    out->pipeline = c->last_pipeline;
+    if (h[30] != 0u) return fail(c, RT_ERR_HIP, "the pooled pipeline gave up waiting for work inside a workgroup; the last frame is incomplete");
     return RT_OK;
 }
 

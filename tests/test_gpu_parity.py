@@ -199,10 +199,12 @@ def test_error_codes(ctx, star):
 
 # ---------------------------------------------------------------------------- pipelines
 # The library has three schedules of the same per-path program: the single persistent kernel
-# (default), the staged one (RT_FLAG_WAVEFRONT: one search launch + one shading launch per
-# ray generation) and the pooled one (RT_FLAG_POOLED: persistent workgroups regrouping four
-# paths per lane through LDS queues).  A pixel's arithmetic never depends on the schedule,
-# so all three must agree bit for bit — with each other at any size, and with the oracle.
+# (RT_FLAG_SINGLE_KERNEL; also what small frames get by default), the staged one
+# (RT_FLAG_WAVEFRONT: one search launch + one shading launch per ray generation) and the pooled
+# one (RT_FLAG_POOLED: persistent workgroups regrouping two paths per lane through LDS queues;
+# what frames with more pixels than pool slots get by default).  A pixel's arithmetic never
+# depends on the schedule, so all three must agree bit for bit — with each other at any size,
+# and with the oracle.
 
 PIPELINES = {"staged": capi.RT_FLAG_WAVEFRONT, "pooled": capi.RT_FLAG_POOLED}
 
@@ -255,9 +257,16 @@ def test_full_size_frames_agree_across_pipelines(ctx, workload):
     preset, W, H, spp, mb, _ = WORKLOADS[workload]
     s = Scene(preset)
     cam = workload_camera(workload, W, H)
-    a = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam)
+    a = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=DEBUG_FLAGS | capi.RT_FLAG_SINGLE_KERNEL)
     b = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
     assert_identical(b, a)
+    assert a["stats"].pipeline == capi.RT_PIPELINE_SINGLE and b["stats"].pipeline == capi.RT_PIPELINE_POOLED
+    # the library's own choice at this size is the pooled schedule, and without the hash its light
+    # queries are bounded: still the same image
+    d = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=0)
+    assert d["stats"].pipeline == capi.RT_PIPELINE_POOLED
+    assert bit_equal_pixels(d["accum"], a["accum"]).all() and np.array_equal(d["bgra"], a["bgra"])
+    assert d["total_rays"] == a["total_rays"]
     assert (a["counts"] == 2).all()
     assert np.isfinite(a["accum"]).all()
     # every pixel's BGRA8 byte is the rounded mean of its accumulated colour (raytracer.comp:992-995)
@@ -267,15 +276,17 @@ def test_full_size_frames_agree_across_pipelines(ctx, workload):
     assert np.array_equal(packed, a["bgra"].view(np.uint32).reshape(H, W))
 
 
+@pytest.mark.parametrize("pipeline", [capi.RT_FLAG_SINGLE_KERNEL, capi.RT_FLAG_POOLED])
 @pytest.mark.parametrize("kind", ["teapot", "directional", "mixed"])
-def test_bounded_light_queries_leave_the_image_unchanged(ctx, teapot, kind):
-    """Without RT_FLAG_PATH_HASH the single kernel bounds its light-visibility searches (they stop
+def test_bounded_light_queries_leave_the_image_unchanged(ctx, teapot, kind, pipeline):
+    """Without RT_FLAG_PATH_HASH the single kernel and the pooled schedule bound their light-visibility searches (they stop
     at the first occluder and ignore anything beyond the light); the accumulated image must
     not change by a bit, only the nearest-hit ids those searches would have reported."""
     s = teapot if kind == "teapot" else _custom_scene(kind)
     W, H = 160, 90
-    exact = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH)
-    fast = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH, flags=capi.RT_FLAG_PRIMARY_IDS)
+    from helpers import DEBUG_FLAGS
+    exact = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
+    fast = gpu_frames(ctx, s, W, H, spp=3, max_bounces=4, frames=2, accel=capi.RT_ACCEL_BVH, flags=capi.RT_FLAG_PRIMARY_IDS | pipeline)
     assert bit_equal_pixels(exact["accum"], fast["accum"]).all()
     assert np.array_equal(exact["counts"], fast["counts"]) and np.array_equal(exact["bgra"], fast["bgra"])
     assert np.array_equal(exact["primary_ids"], fast["primary_ids"]) and exact["total_rays"] == fast["total_rays"]

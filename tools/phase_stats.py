@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
 s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
-for flags in (0, 0, capi.RT_FLAG_TRAVERSAL_STATS):
+for flags in (capi.RT_FLAG_SINGLE_KERNEL, capi.RT_FLAG_SINGLE_KERNEL, capi.RT_FLAG_SINGLE_KERNEL | capi.RT_FLAG_TRAVERSAL_STATS):
     ctx.render_frame(cam, s.push_constants(0.0, 1, True), make_params(spp, mb, capi.RT_ACCEL_BVH, flags=flags))
     st = ctx.stats()
     print(f"flags={flags} kernel_ms={st.kernel_ms:.3f} rays={st.rays} Mrays/s={st.rays/st.kernel_ms/1e3:.1f}")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Render N frames of a workload (for profilers).  python tools/run_frames.py c3 4 [single|staged|pooled] [stats]"""
+"""Render N frames of a workload (for profilers).  python tools/run_frames.py c3 4 [single|staged|pooled|auto] [stats]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import capi
@@ -8,14 +8,15 @@ from raytracer_amd.workloads import WORKLOADS, workload_camera
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 mode = sys.argv[3] if len(sys.argv) > 3 else "single"
-flags = {"staged": capi.RT_FLAG_WAVEFRONT, "pooled": capi.RT_FLAG_POOLED}.get(mode, 0)
+flags = {"staged": capi.RT_FLAG_WAVEFRONT, "pooled": capi.RT_FLAG_POOLED, "single": capi.RT_FLAG_SINGLE_KERNEL, "auto": 0}[mode]
 if len(sys.argv) > 4 and sys.argv[4] == "stats":
     flags |= capi.RT_FLAG_TRAVERSAL_STATS
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
 s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
+strip = tuple(int(v) for v in os.environ.get("RT_STRIP", "0,1,0").split(","))  # rows per strip, ranks, this rank
 for f in range(n):
-    ctx.render_frame(cam, s.push_constants(0.0, f, f == 0), make_params(spp, mb, capi.RT_ACCEL_BVH, flags=flags))
+    ctx.render_frame(cam, s.push_constants(0.0, f, f == 0), make_params(spp, mb, capi.RT_ACCEL_BVH, strip[0], strip[1], strip[2], flags))
     ctx.sync()
     st = ctx.stats()
     print(f"frame {f}: {st.kernel_ms:.3f} ms rays {st.rays} nodes/ray {st.nodes_visited/max(1,st.rays):.2f} tests/ray {st.prims_tested/max(1,st.rays):.2f} "

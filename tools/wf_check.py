@@ -18,7 +18,7 @@ for preset, W, H, spp, mb, accel in [(capi.RT_SCENE_CORNELL_STAR, 96, 54, 3, 6, 
                                       (capi.RT_SCENE_CORNELL_TEAPOT, 160, 90, 2, 4, capi.RT_ACCEL_BVH),
                                       (capi.RT_SCENE_PRESET1, 128, 72, 2, 8, capi.RT_ACCEL_BVH)]:
     s = Scene(preset)
-    a = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=accel, flags=DEBUG_FLAGS)
+    a = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=accel, flags=DEBUG_FLAGS | capi.RT_FLAG_SINGLE_KERNEL)
     for label, fl in (("staged", capi.RT_FLAG_WAVEFRONT), ("pooled", capi.RT_FLAG_POOLED)):
         b = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=accel, flags=DEBUG_FLAGS | fl)
         same = bit_equal_pixels(a["accum"], b["accum"])
@@ -34,7 +34,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
 s = Scene(preset); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
-for label, flags in (("single", 0), ("staged", capi.RT_FLAG_WAVEFRONT), ("pooled", capi.RT_FLAG_POOLED)):
+for label, flags in (("single", capi.RT_FLAG_SINGLE_KERNEL), ("staged", capi.RT_FLAG_WAVEFRONT), ("pooled", capi.RT_FLAG_POOLED)):
     ms = []
     for f in range(5):
         ctx.sync(); t0 = time.perf_counter()
