@@ -164,6 +164,11 @@ typedef struct RtStats {
     int32_t  bvh_depth;     /* maximum depth of the device BVH                                 */
     int32_t  total_prims;   /* spheres + triangles + mesh triangles                            */
     int32_t  pipeline;      /* RT_PIPELINE_* that rendered the last frame                      */
+    uint64_t pool_job_cycles[4]; /* pooled pipeline with TRAVERSAL_STATS: wave cycles spent in
+                                    shading jobs of each kind (first-bounce result, later-bounce
+                                    result, light-query result, sample end); cycles_search then
+                                    holds the search section, cycles_shade the sum of the four and
+                                    cycles_raygen everything else (queue polls, waiting, start)  */
 } RtStats;
 
 typedef struct RtContext RtContext;

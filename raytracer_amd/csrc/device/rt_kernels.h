@@ -51,7 +51,8 @@ struct FrameArgs {
     // (cleared per frame), [8..9] rays of all frames (never cleared); instrumented builds only (cleared
     // per frame): [10..15] wave cycles in refill+raygen / search / shading, [16..17] per-lane traversal
     // iterations, [18..19] per-wave traversal iterations, [20..29] wave cycles of the five parts of
-    // the continuation
+    // the continuation (pooled pipeline: [20..27] items << 32 | jobs per shading queue, [28..29] deep
+    // stack pushes, [30] abort flag, [32..39] wave cycles per shading queue)
     uint32_t* counters;
 };
 

@@ -117,7 +117,11 @@ struct PoolSlot {
     }
 };
 
-RT_DEV uint32_t lds_peek(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+// Volatile accesses to the workgroup's LDS block go through LDS-typed pointers (a volatile
+// access through a generic pointer compiles to a flat load).
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+RT_DEV uint32_t lds_peek(const uint32_t* p) { return *(const volatile lds_u32*)p; }
+RT_DEV void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
 
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
 // LDS and device memory) is visible to the workgroup before the entries can be claimed.
@@ -129,7 +133,7 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     uint32_t pos = 0;
     if (lane_id() == leader) pos = atomicAdd(&L.tail[q], n);
     pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader);
-    if (want) *(volatile uint16_t*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    if (want) *(volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane_id() == leader) atomicAdd(&L.count[q], n);
 }
@@ -156,7 +160,7 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     if (n == 0u) return 0u;
     const uint32_t rank = (uint32_t)__popcll(takers & lanes_below());
     if (((takers >> lane_id()) & 1ull) && rank < n) {
-        volatile uint16_t* e = &L.items[q][(pos + rank) & (kRing - 1)];
+        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(pos + rank) & (kRing - 1)];
         uint32_t v = *e, tries = 0;
         while (v == kEmpty && ++tries < kSpinLimit) v = *e;  // the pusher is between its reservation and its store
         if (v == kEmpty) atomicExch(&L.abort, 1u);
@@ -183,7 +187,7 @@ RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool
         if (lane_id() == leader) {
             while (atomicCAS(&L.res_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            uint32_t next = *(volatile uint32_t*)&L.res_next, end = *(volatile uint32_t*)&L.res_end;
+            uint32_t next = lds_peek(&L.res_next), end = lds_peek(&L.res_end);
             const uint32_t avail = end - next;
             b1 = next;
             c1 = avail < n ? avail : n;
@@ -193,8 +197,8 @@ RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool
                 next = b2 + (n - c1);
                 end = b2 + kChunk;
             }
-            *(volatile uint32_t*)&L.res_next = next;
-            *(volatile uint32_t*)&L.res_end = end;
+            lds_poke(&L.res_next, next);
+            lds_poke(&L.res_end, end);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             atomicExch(&L.res_lock, 0u);
         }
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const int wave = tid >> 6;
     float4* const cold_base = pp.cold + (size_t)blockIdx.x * kPool * 4;
     const float4* __restrict__ recs = (ACCEL == 1) ? sc.prims_bvh : sc.prims_flat;
-    const ShortStack stack{s_stack + tid, pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow, kShortStack, kThreads};
+    const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow), kShortStack, kThreads};
 
     for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
     if (tid < kQueues) { L.count[tid] = 0; L.head[tid] = 0; L.tail[tid] = 0; }
@@ -252,6 +256,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     unsigned long long wave_iters = 0;
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
+    unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0;  // STATS: wave cycles
+    const unsigned long long t_begin = STATS ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
         if (lds_peek(&L.abort) != 0u) break;
@@ -273,6 +279,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (best >= job_thresh || (nothing_to_search && best != 0u)) {
             uint32_t item = 0;
             bool got;
+            const unsigned long long t_job = STATS ? __builtin_readcyclecounter() : 0ull;
             const uint32_t n_items = queue_pop(L, q, ~0ull, best >= job_thresh ? job_thresh : 1u, item, got);
             if (n_items == 0u) continue;
             guard = 0;
@@ -296,10 +303,12 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 queue_push(L, Q_LIGHT, go && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF,
                            i | ((next_stage - WF_LIGHT_SEARCH) << 12));
             }
+            if (STATS) job_cycles[q - Q_FIRST] += __builtin_readcyclecounter() - t_job;
             continue;
         }
 
         // ---- search: retire the lanes whose ray has ended, hand them the next waiting rays
+        const unsigned long long t_search = STATS ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long ended = __ballot(tv.cur == kTravDone && slot >= 0);
         if (ended != 0ull) {
             const bool mine = (tv.cur == kTravDone && slot >= 0);
@@ -366,6 +375,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 }
             }
         }
+        if (STATS) search_cycles += __builtin_readcyclecounter() - t_search;
     }
 
     // ---- counters: one atomic per wave
@@ -389,6 +399,11 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), job_stats[k]);
             atomicAdd((unsigned long long*)(fa.counters + 28), (dp4 << 40) | (dp6 << 20) | dp8);
+            const unsigned long long shade_cycles = job_cycles[0] + job_cycles[1] + job_cycles[2] + job_cycles[3];
+            atomicAdd((unsigned long long*)(fa.counters + 10), __builtin_readcyclecounter() - t_begin - shade_cycles - search_cycles);
+            atomicAdd((unsigned long long*)(fa.counters + 12), search_cycles);
+            atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
+            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }
         if (lds_peek(&L.abort) != 0u) atomicExch(&fa.counters[30], 1u);
     }

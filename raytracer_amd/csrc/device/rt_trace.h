@@ -91,15 +91,24 @@ struct LdsStack {
     RT_DEV void put(int sp, uint32_t v) const { base[sp * kBlock] = v; }
     RT_DEV uint32_t get(int sp) const { return base[sp * kBlock]; }
 };
+// The two parts are addressed through pointers of their own address space: a pointer that may
+// mean either compiles to flat loads, which are slower than LDS reads and make every earlier
+// LDS store wait for completion first.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
 struct ShortStack {
-    uint32_t* base;
-    uint32_t* overflow;
+    lds_u32* base;
+    glb_u32* overflow;
     int depth;
     int stride;  // threads per workgroup
     RT_DEV void put(int sp, uint32_t v) const {
         if (sp < depth) base[sp * stride] = v; else overflow[sp - depth] = v;
     }
-    RT_DEV uint32_t get(int sp) const { return (sp < depth) ? base[sp * stride] : overflow[sp - depth]; }
+    RT_DEV uint32_t get(int sp) const {
+        uint32_t v;
+        if (sp < depth) v = base[sp * stride]; else v = overflow[sp - depth];
+        return v;
+    }
 };
 
 template <typename Stack>

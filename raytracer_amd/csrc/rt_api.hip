@@ -43,7 +43,7 @@ struct RtContext {
     void* d_bgra = nullptr;
     int32_t* d_primary_ids = nullptr;
     uint32_t* d_path_hash = nullptr;
-    uint32_t* d_counters = nullptr;  // 32 x u32, see FrameArgs::counters
+    uint32_t* d_counters = nullptr;  // 48 x u32, see FrameArgs::counters
 
     // path state of the staged pipeline (allocated on first use, grown when needed)
     void* d_pool = nullptr;
@@ -212,8 +212,8 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev_begin);
     hipError_t e3 = hipEventCreate(&c->ev_end);
-    hipError_t e4 = hipMalloc((void**)&c->d_counters, 128);
-    if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 128);
+    hipError_t e4 = hipMalloc((void**)&c->d_counters, 192);
+    if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 192);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
@@ -428,7 +428,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (p.flags & RT_FLAG_PATH_HASH) fa.path_hash = c->d_path_hash;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
-    RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 88, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 152, c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     if (fa.total_slots > 0) {
         bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
@@ -534,8 +534,8 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memset(out, 0, sizeof *out);
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t h[32] = {0};
-    RT_HIP(c, hipMemcpy(h, c->d_counters, 128, hipMemcpyDeviceToHost));
+    uint32_t h[48] = {0};
+    RT_HIP(c, hipMemcpy(h, c->d_counters, 192, hipMemcpyDeviceToHost));
     memcpy(&out->rays, &h[2], 8);
     memcpy(&out->nodes_visited, &h[4], 8);
     memcpy(&out->prims_tested, &h[6], 8);
@@ -546,6 +546,7 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memcpy(&out->lane_iterations, &h[16], 8);
     memcpy(&out->wave_iterations, &h[18], 8);
     memcpy(out->cycles_shade_parts, &h[20], 40);
+    memcpy(out->pool_job_cycles, &h[32], 32);
     if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;

@@ -25,4 +25,8 @@ for f in range(n):
         names = ["first-bounce", "later-bounce", "light-result", "sample-end"]
         dp = list(st.cycles_shade_parts)[4]
         print(f"  pushes at depth >=4: {dp >> 40}, >=6: {(dp >> 20) & 0xfffff}, >=8: {dp & 0xfffff} of {st.nodes_visited} node visits")
+        tot = max(1, st.cycles_raygen + st.cycles_search + st.cycles_shade)
+        jc = list(st.pool_job_cycles)
+        print(f"  wave cycles: search {st.cycles_search / tot:.3f}, other {st.cycles_raygen / tot:.3f}, shading " + ", ".join(
+            f"{n} {c / tot:.3f} ({c / max(1, v >> 32):.0f}/item)" for n, c, v in zip(names, jc, list(st.cycles_shade_parts)[:4])))
         print("  job fill: " + ", ".join(f"{n} {(v >> 32) / max(1, v & 0xffffffff):.1f}/64 x {v & 0xffffffff}" for n, v in zip(names, list(st.cycles_shade_parts)[:4])), flush=True)
