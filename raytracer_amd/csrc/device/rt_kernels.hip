@@ -28,16 +28,7 @@ template <bool STATS>
 RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack stack, Trav& tv, float t_occl, bool wants_result,
                             int exit_quota, uint32_t& n_nodes, uint32_t& n_tests, uint32_t& n_iters,
                             unsigned long long& wave_iters) {
-    // Slab arithmetic runs on a direction with no zero component; the boxes are padded on
-    // the host by far more than the half-ulp origin perturbation the fused form implies.
-    float dx = (g_abs(rd.x) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.x) : rd.x;
-    float dy = (g_abs(rd.y) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.y) : rd.y;
-    float dz = (g_abs(rd.z) < 1e-30f) ? __builtin_copysignf(1e-30f, rd.z) : rd.z;
-    // The box test only has to be conservative, so the hardware's approximate reciprocal
-    // (1 ulp) is enough here; the exact arithmetic is kept for the primitive tests.
-    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
-    const float ox = -(ro.x * ix), oy = -(ro.y * iy), oz = -(ro.z * iz);
-    const float4* __restrict__ nodes = sc.nodes;
+    const Slab sl = make_slab(ro, rd);
 
     for (;;) {
         const unsigned long long m_node = __ballot(tv.cur >= 0 && tv.cur != kTravDone);
@@ -46,51 +37,15 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack 
         const unsigned long long m_done = __ballot(wants_result && tv.cur == kTravDone);
         if (__popcll(m_done) >= exit_quota) break;
         if (STATS) wave_iters++;
-        if (__popcll(m_node) >= __popcll(m_leaf)) {
+        if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
             if (tv.cur >= 0 && tv.cur != kTravDone) {
-                const float4 q0 = nodes[4 * tv.cur + 0];
-                const float4 q1 = nodes[4 * tv.cur + 1];
-                const float4 q2 = nodes[4 * tv.cur + 2];
-                const float4 q3 = nodes[4 * tv.cur + 3];
+                trav_node_step(sc.nodes, sl, stack, tv);
                 if (STATS) { n_nodes++; n_iters++; }
-                // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
-                float a0 = __builtin_fmaf(q0.x, ix, ox), b0 = __builtin_fmaf(q0.w, ix, ox);
-                float a1 = __builtin_fmaf(q0.y, iy, oy), b1 = __builtin_fmaf(q1.x, iy, oy);
-                float a2 = __builtin_fmaf(q0.z, iz, oz), b2 = __builtin_fmaf(q1.y, iz, oz);
-                float tmin0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), 0.0f));
-                float tmax0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), tv.best_t));
-                float c0 = __builtin_fmaf(q1.z, ix, ox), d0 = __builtin_fmaf(q2.y, ix, ox);
-                float c1 = __builtin_fmaf(q1.w, iy, oy), d1 = __builtin_fmaf(q2.z, iy, oy);
-                float c2 = __builtin_fmaf(q2.x, iz, oz), d2 = __builtin_fmaf(q2.w, iz, oz);
-                float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
-                float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), tv.best_t));
-                // an unused child slot (child index -1, inverted box) must never be entered: the slab
-                // arithmetic on its infinities would report a hit
-                const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.x) >= 0);
-                const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.y) >= 0);
-                int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
-                int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
-                if (hit0 && hit1) {
-                    if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
-                    stack.put(tv.sp, (uint32_t)r1);
-                    tv.sp++;
-                    tv.cur = r0;
-                } else if (hit0) {
-                    tv.cur = r0;
-                } else if (hit1) {
-                    tv.cur = r1;
-                } else {
-                    trav_pop(tv, stack);
-                }
             }
         } else {
             if (tv.cur < 0) {
-                const int first = tv.cur & 0x0fffffff;
-                const int left = (tv.cur >> 28) & 7;  // primitives after this one
-                intersect_record(sc.prims_bvh, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
+                trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
                 if (STATS) { n_tests++; n_iters++; }
-                if (left == 0) trav_pop(tv, stack);
-                else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 1) << 28) | (uint32_t)(first + 1));
                 // a light-visibility ray is decided once something lies clearly in front of the light
                 if (tv.best_t < t_occl) tv.cur = kTravDone;
             }

@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 const unsigned long long m_leaf = __ballot(tv.cur < 0);
                 if ((m_node | m_leaf) == 0ull) break;
                 if (STATS) wave_iters++;
-                if (__popcll(m_node) >= __popcll(m_leaf)) {
+                if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
                     if (tv.cur >= 0 && tv.cur != kTravDone) {
                         const int sp_before = tv.sp;
                         trav_node_step(sc.nodes, sl, stack, tv);

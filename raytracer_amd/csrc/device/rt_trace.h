@@ -162,12 +162,13 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
     float c2 = __builtin_fmaf(q2.x, sl.iz, sl.oz), d2 = __builtin_fmaf(q2.w, sl.iz, sl.oz);
     float tmin1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), 0.0f));
     float tmax1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), tv.best_t));
-    // an unused child slot (child index -1, inverted box) must never be entered: the slab
+    // q3 = the two children as cursor words (encode_child, done at upload) and their primitive
+    // counts; an unused child slot (count -1, inverted box) must never be entered: the slab
     // arithmetic on its infinities would report a hit
-    const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.x) >= 0);
-    const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.y) >= 0);
-    int r0 = encode_child(__float_as_int(q3.x), __float_as_int(q3.z));
-    int r1 = encode_child(__float_as_int(q3.y), __float_as_int(q3.w));
+    const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.z) >= 0);
+    const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.w) >= 0);
+    int r0 = __float_as_int(q3.x);
+    int r1 = __float_as_int(q3.y);
     if (hit0 && hit1) {
         if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
         stack.put(tv.sp, (uint32_t)r1);

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kBlock) wf_search_kernel(const DeviceScene sc,
             continue;
         }
         if (STATS) wave_iters++;
-        if (__popcll(m_node) >= __popcll(m_leaf)) {
+        if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
             if (tv.cur >= 0 && tv.cur != kTravDone) {
                 trav_node_step(sc.nodes, sl, stack, tv);
                 if (STATS) n_nodes++;

@@ -24,6 +24,28 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
             for (int j = 0; j < 8; ++j) {
                 a0 = c / a0 + m; a1 = c / a1 + m; a2 = c / a2 + m; a3 = c / a3 + m; a4 = c / a4 + m; a5 = c / a5 + m; a6 = c / a6 + m; a7 = c / a7 + m;
             }
+        } else if (MODE == 4) {  // min/max chain (the slab test)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0 = fminf(a0, a1); a1 = fmaxf(a1, a2); a2 = fminf(a2, a3); a3 = fmaxf(a3, a4); a4 = fminf(a4, a5); a5 = fmaxf(a5, a6); a6 = fminf(a6, a7); a7 = fmaxf(a7, a0);
+            }
+        } else if (MODE == 5) {  // integer add / and / shift
+            unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1), u2 = __float_as_uint(a2), u3 = __float_as_uint(a3), u4 = __float_as_uint(a4), u5 = __float_as_uint(a5), u6 = __float_as_uint(a6), u7 = __float_as_uint(a7);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                u0 = u0 + u7; u1 = u1 ^ u0; u2 = (u2 << 1) | 1u; u3 = u3 + u2; u4 = u4 ^ u3; u5 = (u5 >> 1) ^ 5u; u6 = u6 + u5; u7 = u7 ^ u6;
+            }
+            a0 = __uint_as_float(u0); a1 = __uint_as_float(u1); a2 = __uint_as_float(u2); a3 = __uint_as_float(u3); a4 = __uint_as_float(u4); a5 = __uint_as_float(u5); a6 = __uint_as_float(u6); a7 = __uint_as_float(u7);
+        } else if (MODE == 6) {  // compare + select
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0 = a0 < a1 ? a2 : a3; a1 = a1 < a2 ? a3 : a4; a2 = a2 < a3 ? a4 : a5; a3 = a3 < a4 ? a5 : a6; a4 = a4 < a5 ? a6 : a7; a5 = a5 < a6 ? a7 : a0; a6 = a6 < a7 ? a0 : a1; a7 = a7 < a0 ? a1 : a2;
+            }
+        } else if (MODE == 7) {  // plain mul / add (no fma)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0 = a0 * m; a1 = a1 + c; a2 = a2 * m; a3 = a3 + c; a4 = a4 * m; a5 = a5 + c; a6 = a6 * m; a7 = a7 + c;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -55,5 +77,9 @@ int main() {
     for (int w : {1, 2, 4}) { run<1>("rcp", w, d); }
     for (int w : {1, 2, 4}) { run<2>("div", w, d); }
     for (int w : {1, 2, 4}) { run<3>("sqrt", w, d); }
+    for (int w : {1, 2, 3, 4}) { run<4>("minmax", w, d); }
+    for (int w : {1, 2, 3, 4}) { run<5>("int", w, d); }
+    for (int w : {1, 2, 3, 4}) { run<6>("cmpsel", w, d); }
+    for (int w : {1, 2, 3, 4}) { run<7>("muladd", w, d); }
     return 0;
 }
