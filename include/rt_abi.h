@@ -292,6 +292,48 @@ int rt_camera_default(RtCamera* out, int32_t width, int32_t height);
 int rt_push_constants(RtPushConstants* out, const RtScene* s, float time, uint32_t frame_count,
                       int reset_accumulation);
 
+/* ------------------------------------------------------------------ camera controller
+ * The application's interactive camera and its per-frame seeding policy as a headless
+ * state machine: RaytracingApp's camera/accumulation members (main.cpp:250-273), mainLoop's
+ * clock step (283-285), processInput (402-496), the mouse callbacks (499-550), updateCamera
+ * (554-565), the frame's camera block and push constants (1331-1340) and showFPS's frame
+ * counter (2156-2174).  Window-system events become explicit calls.  It starts from the pose
+ * after the application's first updateCamera(): position (2.75,2.75,-6), yaw 180, pitch 0. */
+typedef struct RtController RtController;
+
+enum { RT_KEY_W = 1u, RT_KEY_S = 2u, RT_KEY_A = 4u, RT_KEY_D = 8u, RT_KEY_SPACE = 16u,
+       RT_KEY_LEFT_CONTROL = 32u, RT_KEY_LEFT_SHIFT = 64u, RT_KEY_Q = 128u, RT_KEY_E = 256u,
+       RT_KEY_F = 512u, RT_KEY_R = 1024u, RT_KEY_X = 2048u,
+       RT_KEY_RELEASE_MOUSE = 4096u, /* ESCAPE, LEFT_ALT or TAB (main.cpp:490-495)          */
+       RT_KEY_K = 8192u };           /* asks the window to close (main.cpp:445-446)          */
+
+typedef struct RtControllerState {
+    float pos[3], front[3], up[3];
+    float yaw, pitch, roll, fov;   /* degrees                                                */
+    float last_frame;              /* the clock value that becomes pushConstants.time        */
+    int32_t frame_count;           /* the counter that becomes pushConstants.frameCount      */
+    int32_t mouse_captured, reset_accumulation, accumulation_on, should_close;
+} RtControllerState;
+
+int rt_controller_create(RtController** out);
+int rt_controller_destroy(RtController* c);
+int rt_controller_get(const RtController* c, RtControllerState* out);
+/* planeMode (main.cpp:88-90): constant forward motion instead of the movement keys. */
+int rt_controller_set_plane_mode(RtController* c, int on);
+/* One main-loop iteration up to drawFrame: the clock step (deltaTime = now - lastFrame) and
+ * processInput with the keys that are down (a mask of RT_KEY_*). */
+int rt_controller_begin_frame(RtController* c, double now_seconds, uint32_t keys, float* delta_time_out);
+int rt_controller_mouse_button(RtController* c, int left_pressed);      /* focus_callback  */
+int rt_controller_mouse_move(RtController* c, double xpos, double ypos); /* mouse_callback  */
+int rt_controller_scroll(RtController* c, double yoffset);               /* scroll callback */
+/* The frame's inputs: push constants (time = the clock value of begin_frame, frameCount, reset
+ * rule of main.cpp:1430-1434) and camera block; clears the pending reset like
+ * updatePushConstantsPost. */
+int rt_controller_frame_inputs(RtController* c, const RtScene* s, int32_t width, int32_t height,
+                               RtCamera* cam, RtPushConstants* pc);
+/* showFPS: frameCount++, and back to 0 once a second has passed since the window began. */
+int rt_controller_end_frame(RtController* c, double now_seconds);
+
 /* Builds the host BVH of a scene (no GPU needed), checks its structure (every primitive in
  * exactly one leaf, boxes nested, depth within the traversal limit; RT_ERR_UNSUPPORTED if
  * not) and reports node count, depth, primitive count and SAH cost. */

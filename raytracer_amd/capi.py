@@ -115,6 +115,19 @@ class RtSceneView(C.Structure):
                 ("total_lights", C.c_int32), ("lights_strength_sum", C.c_float)]
 
 
+
+class RtControllerState(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("front", C.c_float * 3), ("up", C.c_float * 3),
+                ("yaw", C.c_float), ("pitch", C.c_float), ("roll", C.c_float), ("fov", C.c_float),
+                ("last_frame", C.c_float), ("frame_count", C.c_int32),
+                ("mouse_captured", C.c_int32), ("reset_accumulation", C.c_int32),
+                ("accumulation_on", C.c_int32), ("should_close", C.c_int32)]
+
+
+RT_KEY_W, RT_KEY_S, RT_KEY_A, RT_KEY_D, RT_KEY_SPACE, RT_KEY_LEFT_CONTROL, RT_KEY_LEFT_SHIFT = 1, 2, 4, 8, 16, 32, 64
+RT_KEY_Q, RT_KEY_E, RT_KEY_F, RT_KEY_R, RT_KEY_X, RT_KEY_RELEASE_MOUSE, RT_KEY_K = 128, 256, 512, 1024, 2048, 4096, 8192
+
+
 # name -> (restype, argtypes); every symbol include/rt_abi.h declares
 _P = C.c_void_p
 PROTOTYPES = {
@@ -155,6 +168,16 @@ PROTOTYPES = {
                                  C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_int32]),
     "rt_camera_default": (C.c_int, [C.POINTER(RtCamera), C.c_int32, C.c_int32]),
     "rt_push_constants": (C.c_int, [C.POINTER(RtPushConstants), _P, C.c_float, C.c_uint32, C.c_int]),
+    "rt_controller_create": (C.c_int, [C.POINTER(_P)]),
+    "rt_controller_destroy": (C.c_int, [_P]),
+    "rt_controller_get": (C.c_int, [_P, C.POINTER(RtControllerState)]),
+    "rt_controller_set_plane_mode": (C.c_int, [_P, C.c_int]),
+    "rt_controller_begin_frame": (C.c_int, [_P, C.c_double, C.c_uint32, C.POINTER(C.c_float)]),
+    "rt_controller_mouse_button": (C.c_int, [_P, C.c_int]),
+    "rt_controller_mouse_move": (C.c_int, [_P, C.c_double, C.c_double]),
+    "rt_controller_scroll": (C.c_int, [_P, C.c_double]),
+    "rt_controller_frame_inputs": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.POINTER(RtCamera), C.POINTER(RtPushConstants)]),
+    "rt_controller_end_frame": (C.c_int, [_P, C.c_double]),
     "rt_scene_bvh_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_float)]),
 }

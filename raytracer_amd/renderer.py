@@ -132,6 +132,60 @@ def look_camera(pos, front, up, fov_degrees: float, width: int, height: int) -> 
     return cam
 
 
+class Controller:
+    """The application's camera controller and frame seeding policy (RaytracingApp's camera state,
+    processInput, mouse callbacks, updateCamera, showFPS: src/main.cpp:250-273, 283-288, 402-565,
+    1424-1442, 2156-2174) driven by explicit events instead of a window."""
+
+    def __init__(self):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        rc = self._lib.rt_controller_create(C.byref(self._h))
+        if rc != capi.RT_OK:
+            raise RtError(rc, "rt_controller_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rt_controller_destroy(h)
+
+    def _chk(self, rc, what):
+        if rc != capi.RT_OK:
+            raise RtError(rc, what)
+
+    @property
+    def state(self) -> capi.RtControllerState:
+        st = capi.RtControllerState()
+        self._chk(self._lib.rt_controller_get(self._h, C.byref(st)), "rt_controller_get")
+        return st
+
+    def set_plane_mode(self, on: bool) -> None:
+        self._chk(self._lib.rt_controller_set_plane_mode(self._h, 1 if on else 0), "rt_controller_set_plane_mode")
+
+    def begin_frame(self, now_seconds: float, keys: int = 0) -> float:
+        dt = C.c_float()
+        self._chk(self._lib.rt_controller_begin_frame(self._h, float(now_seconds), int(keys), C.byref(dt)), "rt_controller_begin_frame")
+        return dt.value
+
+    def mouse_button(self, left_pressed: bool = True) -> None:
+        self._chk(self._lib.rt_controller_mouse_button(self._h, 1 if left_pressed else 0), "rt_controller_mouse_button")
+
+    def mouse_move(self, x: float, y: float) -> None:
+        self._chk(self._lib.rt_controller_mouse_move(self._h, float(x), float(y)), "rt_controller_mouse_move")
+
+    def scroll(self, yoffset: float) -> None:
+        self._chk(self._lib.rt_controller_scroll(self._h, float(yoffset)), "rt_controller_scroll")
+
+    def frame_inputs(self, scene: "Scene", width: int, height: int):
+        cam, pc = capi.RtCamera(), capi.RtPushConstants()
+        self._chk(self._lib.rt_controller_frame_inputs(self._h, scene._h, int(width), int(height), C.byref(cam), C.byref(pc)),
+                  "rt_controller_frame_inputs")
+        return cam, pc
+
+    def end_frame(self, now_seconds: float) -> None:
+        self._chk(self._lib.rt_controller_end_frame(self._h, float(now_seconds)), "rt_controller_end_frame")
+
+
 def make_params(spp: int = 5, max_bounces: int = 20, accel: int = capi.RT_ACCEL_BVH, strip_rows: int = 0,
                 strip_count: int = 1, strip_index: int = 0, flags: int = 0) -> capi.RtParams:
     return capi.RtParams(int(spp), int(max_bounces), int(accel), int(strip_rows), int(strip_count), int(strip_index),

@@ -28,6 +28,18 @@ def oracle_frames(scene: Scene, width, height, spp, max_bounces, frames=1, math_
     return out
 
 
+def oracle_render(scene: Scene, width, height, spp, max_bounces, inputs, math_mode=0, threads=8):
+    """Oracle frames for an explicit sequence of (camera block, push constants) pairs."""
+    osc = ob.OracleScene(scene.arrays())
+    acc = cnt = None
+    out = None
+    for cam, pc in inputs:
+        out = ob.render(osc, cam, pc, width, height, spp, max_bounces, math_mode=math_mode, threads=threads, accum=acc,
+                        counts=cnt)
+        acc, cnt = out["accum"], out["counts"]
+    return out
+
+
 def gpu_frames(ctx: Context, scene: Scene, width, height, spp, max_bounces, frames=1, accel=capi.RT_ACCEL_BVH,
                camera=None, time=0.0, flags=DEBUG_FLAGS, strip=(0, 1, 0), upload=True, resize=True):
     cam = camera or default_camera(width, height)

@@ -13,7 +13,7 @@ import pytest
 
 from helpers import bit_equal_pixels, gpu_frames, oracle_frames
 from raytracer_amd import capi
-from raytracer_amd.renderer import Context, Scene
+from raytracer_amd.renderer import Context, Controller, Scene, make_params
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +89,34 @@ def test_accumulation_over_frames(ctx, star):
     g = gpu_frames(ctx, star, W, H, spp=1, max_bounces=4, frames=3, accel=capi.RT_ACCEL_FLAT)
     assert (g["counts"] == 3).all()
     assert_identical(g, o)
+
+
+def test_controller_driven_session_accumulates_and_resets(ctx, star):
+    """A session driven by the camera controller (main.cpp:283-290 loop order): frames accumulate
+    while the camera rests, a movement key restarts the accumulation, and every frame equals the
+    oracle's rendering of the same camera block and push constants."""
+    from helpers import oracle_render
+    W, H = 48, 27
+    ctl = Controller()
+    ctx.upload_scene(star)
+    ctx.resize(W, H)
+    params = make_params(1, 3, capi.RT_ACCEL_FLAT)
+    inputs = []
+    clock = 0.0
+    for keys in (0, 0, 0, capi.RT_KEY_W, 0):
+        clock += 0.02
+        ctl.begin_frame(clock, keys)
+        cam, pc = ctl.frame_inputs(star, W, H)
+        ctx.render_frame(cam, pc, params)
+        ctl.end_frame(clock)
+        inputs.append((cam, pc))
+    acc, cnt = ctx.read_accum()
+    assert [pc.reset_frame_accumulation for _, pc in inputs] == [1, 0, 0, 1, 0]
+    assert [pc.frameCount for _, pc in inputs] == [0, 1, 2, 3, 4]
+    assert (cnt == 2).all()   # the frame with the W key and the one after it
+    o = oracle_render(star, W, H, 1, 3, inputs)
+    assert np.array_equal(cnt, o["counts"])
+    assert bit_equal_pixels(acc, o["accum"]).all()
 
 
 def _custom_scene(kind):
