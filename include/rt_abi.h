@@ -140,7 +140,10 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
        RT_FLAG_POOLED      = 32u,  /* pooled pipeline: one persistent launch whose workgroups keep
                                       two paths per lane, their hot state in LDS, and regroup them
                                       by kind of work through queues in LDS; same results         */
-       RT_FLAG_SINGLE_KERNEL = 64u /* the single persistent kernel, one path per lane              */ };
+       RT_FLAG_SINGLE_KERNEL = 64u, /* the single persistent kernel, one path per lane             */
+       RT_FLAG_FIXED_TILE_ORDER = 128u /* hand the image's 8x8 tiles out in image order instead of
+                                      dearest-first as measured on the previous frame of the same
+                                      size; same results, only the schedule differs              */ };
 /* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: the
  * pooled pipeline when the BVH is used and the frame has at least as many pixels as the pools have
  * slots (1536 per CU), the single kernel otherwise.  All pipelines give the same bits. */

@@ -35,6 +35,7 @@ RT_FLAG_TRAVERSAL_STATS = 8
 RT_FLAG_WAVEFRONT = 16
 RT_FLAG_POOLED = 32
 RT_FLAG_SINGLE_KERNEL = 64
+RT_FLAG_FIXED_TILE_ORDER = 128
 RT_PIPELINE_SINGLE, RT_PIPELINE_STAGED, RT_PIPELINE_POOLED = 0, 1, 2
 
 RT_SCENE_EMPTY = 0

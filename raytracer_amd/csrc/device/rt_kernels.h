@@ -35,8 +35,8 @@ struct FrameArgs {
     int32_t spp, max_bounces;
     int32_t strip_rows, strip_count, strip_index;  // strip_rows <= 0: all rows
     int32_t owned_rows;                             // rows this context renders
-    int32_t tiles_x;                                // ceil(width / 8)
-    uint32_t total_slots;                           // tiles_x * ceil(owned_rows / 8) * 64
+    int32_t tiles_x;                                // blocks per row: ceil(width / (8 << kBlockTilesLog2))
+    uint32_t total_slots;                           // blocks * pixels per block (blocks cover the owned rows)
     uint32_t flags;
     int32_t exit_quota_pct;  // the search loop returns once this share of the wave's busy lanes has finished
     int32_t accel;           // RT_ACCEL_*: which record array the search results index
@@ -54,9 +54,20 @@ struct FrameArgs {
     // the continuation (pooled pipeline: [20..27] items << 32 | jobs per shading queue, [28..29] deep
     // stack pushes, [30] abort flag, [32..39] wave cycles per shading queue)
     uint32_t* counters;
+    // Order in which the image's pixel blocks are handed out: slot block k renders image block
+    // tile_order[k] (null: k itself).  tile_cost (may be null) receives, per image block, the path
+    // segments traced for it this frame; the next frame's order is made from it.
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
 };
 
 enum { kBlock = 256, kStackDepth = 32 };
+// Pixels are handed out in blocks of (1 << kBlockTilesLog2)^2 tiles of 8x8 pixels; the block is
+// the unit of the frame-to-frame order, a tile (64 consecutive slots) stays one wave's worth.
+#ifndef RT_BLOCK_TILES_LOG2
+#define RT_BLOCK_TILES_LOG2 0
+#endif
+enum { kBlockTilesLog2 = RT_BLOCK_TILES_LOG2, kBlockPixLog2 = 3 + kBlockTilesLog2, kBlockSlotsLog2 = 2 * kBlockPixLog2 };
 
 // Path state of the staged pipeline: one slot per pixel in flight, structure of arrays in
 // device memory.  `stage` says what a slot waits for between launches.
@@ -103,6 +114,9 @@ hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, u
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
                        int refill_min, int burst, int job_min, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
+// Turns the per-tile costs of the frame just rendered into the next frame's tile order (most
+// expensive class first, image order within a class) and clears the costs.
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);
 
 }  // namespace rtd

@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
     V3 ro = v3(0.0f), rd = v3(0.0f, 0.0f, 1.0f);  // path ray
     V3 att = v3(1.0f), col = v3(0.0f), pix = v3(0.0f);
     uint32_t phash = 0;
+    uint32_t cost = 0;  // path segments of the pixel so far
     // saved across a light-visibility search
     Hit sh;
     sh.p = v3(0.0f); sh.normal = v3(0.0f); sh.mat = 0; sh.t = 0.0f; sh.front_face = false;
@@ -115,14 +116,8 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             if (res_left != 0u) {
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (state == ST_IDLE && rank < res_left) {
-                    const uint32_t slot = res_next + rank;
-                    const uint32_t tile = slot >> 6, in = slot & 63u;
-                    const int x = (int)(tile % (uint32_t)fa.tiles_x) * 8 + (int)(in & 7u);
-                    const int r = (int)(tile / (uint32_t)fa.tiles_x) * 8 + (int)(in >> 3);
-                    if (x < fa.width && r < fa.owned_rows) {
-                        int y = r;
-                        if (fa.strip_rows > 0)
-                            y = ((r / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (r % fa.strip_rows);
+                    int x, y;
+                    if (slot_to_pixel(fa, res_next + rank, x, y)) {
                         px = x;
                         py = y;
                         // raytracer.comp:959-961
@@ -130,6 +125,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                         pix = v3(0.0f);
                         sample = 0;
                         phash = 0;
+                        cost = 0;
                         state = -1;  // start a sample below
                     }
                 }
@@ -384,6 +380,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
         if (end_sample) {
             pix = pix + g_clamp(col, 0.0f, 1.0f);  // raytracer.comp:925/929, 974
             sample++;
+            cost += (uint32_t)(bounce + 1);
             if (sample < fa.spp) {
                 state = -1;
             } else {
@@ -402,6 +399,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                 fa.counts[idx] = n;
                 fa.bgra[idx] = resolve_pixel(a, n);
                 if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[idx] = phash;
+                report_pixel_cost(fa, px, py, cost);
                 state = ST_IDLE;
             }
         }
@@ -510,6 +508,87 @@ hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, 
                      : launch_persistent(render_kernel<1, false>, sc, fa, cu_count, stream);
     return stats ? launch_persistent(render_kernel<0, true>, sc, fa, cu_count, stream)
                  : launch_persistent(render_kernel<0, false>, sc, fa, cu_count, stream);
+}
+
+namespace {
+
+constexpr int kOrderThreads = 1024;
+constexpr int kMaxClasses = 64;
+
+// Exclusive prefix sum of one value per thread over the workgroup (kOrderThreads threads).
+RT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(inc, off);
+        if (lane >= off) inc += up;
+    }
+    __syncthreads();  // s_wave may still be read from the previous call
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < kOrderThreads / 64; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    total = all;
+    return before + inc - v;
+}
+
+// One workgroup.  Tiles are put into `classes` classes by cost relative to the dearest tile and
+// listed class by class, dearest first, in image order within a class (neighbouring tiles stay
+// neighbours: their rays share nodes and materials).  Long pixels thus start early and the
+// frame ends on short ones.  The costs are cleared for the next frame.
+__global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n,
+                                                                   int classes) {
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_wave[kOrderThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + kOrderThreads - 1) / kOrderThreads;
+    const uint32_t begin = tid * chunk < n ? tid * chunk : n;
+    const uint32_t end = begin + chunk < n ? begin + chunk : n;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = begin; i < end; ++i) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const unsigned long long scale = (unsigned long long)s_max + 1ull;
+    uint32_t cnt[kMaxClasses];
+    for (int c = 0; c < kMaxClasses; ++c) cnt[c] = 0;
+    for (uint32_t i = begin; i < end; ++i) {
+        const int c = classes - 1 - (int)(((unsigned long long)cost[i] * (unsigned long long)classes) / scale);
+        for (int k = 0; k < kMaxClasses; ++k) cnt[k] += (k == c) ? 1u : 0u;
+    }
+    uint32_t offs[kMaxClasses];
+    uint32_t base = 0;
+    for (int c = 0; c < kMaxClasses; ++c) {
+        uint32_t total = 0;
+        offs[c] = 0;
+        if (c < classes) {  // uniform across the workgroup
+            offs[c] = base + block_exclusive_scan(cnt[c], s_wave, total);
+            base += total;
+        }
+    }
+    for (uint32_t i = begin; i < end; ++i) {
+        const int c = classes - 1 - (int)(((unsigned long long)cost[i] * (unsigned long long)classes) / scale);
+        uint32_t at = 0;
+        for (int k = 0; k < kMaxClasses; ++k) {
+            if (k == c) { at = offs[k]; offs[k] += 1u; }
+        }
+        order[at] = i;
+        cost[i] = 0u;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    classes = classes < 1 ? 1 : (classes > kMaxClasses ? kMaxClasses : classes);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, tile_cost, tile_order, n_tiles, classes);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream) {

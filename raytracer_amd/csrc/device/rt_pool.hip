@@ -75,7 +75,7 @@ struct PoolLds {
     uint32_t abort;                  // set when a bound on waiting was exceeded (never in a correct run)
 };
 
-// Accessor of slot i: hot fields in LDS, cold record (4 float4: pixel sum | normal, s_d |
+// Accessor of slot i: hot fields in LDS, cold record (4 float4: pixel sum, pixel cost | normal, s_d |
 // path direction, light | material bits) in device memory.
 struct PoolSlot {
     PoolLds& L;
@@ -98,8 +98,8 @@ struct PoolSlot {
     RT_DEV void get_hit(float& t, int& idx) const { t = L.hit_t[i]; idx = L.hit_idx[i]; }
     RT_DEV V3 get_col() const { return v3(L.col[0][i], L.col[1][i], L.col[2][i]); }
     RT_DEV void put_col(V3 v) const { L.col[0][i] = v.x; L.col[1][i] = v.y; L.col[2][i] = v.z; }
-    RT_DEV V3 get_pix() const { return xyz(cold[0]); }
-    RT_DEV void put_pix(V3 v) const { cold[0] = f4(v, 0.0f); }
+    RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
+    RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t) const {}
     // bounds of a light query's search, kept in the hit fields until the search overwrites them
     RT_DEV void put_search_bounds(float t_max, float t_occl) const { L.hit_t[i] = t_max; L.hit_idx[i] = __float_as_int(t_occl); }

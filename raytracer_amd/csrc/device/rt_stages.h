@@ -42,8 +42,8 @@ struct GlobalSlot {
     RT_DEV void get_hit(float& t, int& idx) const { const uint2 r = pp.hit[s]; t = __uint_as_float(r.x); idx = (int)r.y; }
     RT_DEV V3 get_col() const { return xyz(pp.col[s]); }
     RT_DEV void put_col(V3 v) const { pp.col[s] = f4(v, 0.0f); }
-    RT_DEV V3 get_pix() const { return xyz(pp.pix[s]); }
-    RT_DEV void put_pix(V3 v) const { pp.pix[s] = f4(v, 0.0f); }
+    RT_DEV V3 get_pix(float& cost) const { const float4 v = pp.pix[s]; cost = v.w; return xyz(v); }
+    RT_DEV void put_pix(V3 v, float cost) const { pp.pix[s] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t st) const { pp.stage[s] = st; }
     RT_DEV void put_search_bounds(float, float) const {}  // the staged search always finds the true nearest hit
     RT_DEV void put_light_query(const LightQuery& q) const {
@@ -209,10 +209,12 @@ RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
     int bounce;
     sl.get_ctl(seed, pixel, sample, bounce);
     sample += 1u;
-    V3 pix = sl.get_pix() + g_clamp(sl.get_col(), 0.0f, 1.0f);
+    float cost;  // path segments of the pixel so far (a small integer, exact in binary32)
+    V3 pix = sl.get_pix(cost) + g_clamp(sl.get_col(), 0.0f, 1.0f);
+    cost += (float)(bounce + 1);
     (void)sl.get_att(phash);
     if ((int)sample < fa.spp) {
-        sl.put_pix(pix);
+        sl.put_pix(pix, cost);
         start_sample(fa, sl, seed, pixel, sample, phash);
         alive = true;
     } else {
@@ -229,6 +231,8 @@ RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
         fa.counts[pixel] = n;
         fa.bgra[pixel] = resolve_pixel(a, n);
         if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[pixel] = phash;
+        const int py = (int)(pixel / (uint32_t)fa.width);
+        report_pixel_cost(fa, (int)pixel - py * fa.width, py, (uint32_t)cost);
         sl.put_stage(WF_IDLE);
         alive = false;
     }
@@ -238,7 +242,7 @@ RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
 template <typename Slot>
 RT_DEV void start_pixel(const FrameArgs& fa, const Slot& sl, int x, int y) {
     const uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
-    sl.put_pix(v3(0.0f));
+    sl.put_pix(v3(0.0f), 0.0f);
     start_sample(fa, sl, seed, (uint32_t)(y * fa.width + x), 0u, 0u);
 }
 

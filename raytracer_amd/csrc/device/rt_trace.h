@@ -252,13 +252,26 @@ RT_DEV void generate_ray(const FrameArgs& fa, int px, int py, uint32_t& seed, V3
 // Pixel slot -> image coordinates: slots walk 8x8 tiles row-major over the rows this
 // context owns; with a strip partition the owned rows are every strip_count-th strip.
 RT_DEV bool slot_to_pixel(const FrameArgs& fa, uint32_t slot, int& x, int& y) {
-    const uint32_t tile = slot >> 6, in = slot & 63u;
-    x = (int)(tile % (uint32_t)fa.tiles_x) * 8 + (int)(in & 7u);
-    const int r = (int)(tile / (uint32_t)fa.tiles_x) * 8 + (int)(in >> 3);
+    uint32_t block = slot >> kBlockSlotsLog2;
+    const uint32_t in = slot & ((1u << kBlockSlotsLog2) - 1u);
+    if (fa.tile_order != nullptr) block = fa.tile_order[block];
+    // inside a block: 8x8 tiles in row-major order, 64 consecutive slots per tile
+    const uint32_t tile = in >> 6, p = in & 63u;
+    const uint32_t tmask = (1u << kBlockTilesLog2) - 1u;
+    x = (int)(((block % (uint32_t)fa.tiles_x) << kBlockPixLog2) + ((tile & tmask) << 3) + (p & 7u));
+    const int r = (int)(((block / (uint32_t)fa.tiles_x) << kBlockPixLog2) + ((tile >> kBlockTilesLog2) << 3) + (p >> 3));
     if (x >= fa.width || r >= fa.owned_rows) return false;
     y = r;
     if (fa.strip_rows > 0) y = ((r / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (r % fa.strip_rows);
     return true;
+}
+
+// A finished pixel reports what it cost (path segments over all its samples) to its image block.
+RT_DEV void report_pixel_cost(const FrameArgs& fa, int x, int y, uint32_t cost) {
+    if (fa.tile_cost == nullptr) return;
+    int r = y;
+    if (fa.strip_rows > 0) r = ((y / fa.strip_rows) / fa.strip_count) * fa.strip_rows + (y % fa.strip_rows);
+    atomicAdd(&fa.tile_cost[(uint32_t)(r >> kBlockPixLog2) * (uint32_t)fa.tiles_x + (uint32_t)(x >> kBlockPixLog2)], cost);
 }
 
 // The second half of sample_light (raytracer.comp:617-626, 636-644, 662-671): what arrives

@@ -44,6 +44,18 @@ struct RtContext {
     int32_t* d_primary_ids = nullptr;
     uint32_t* d_path_hash = nullptr;
     uint32_t* d_counters = nullptr;  // 48 x u32, see FrameArgs::counters
+    // tile order fed back from frame to frame (see FrameArgs::tile_order)
+    uint32_t* d_tile_order = nullptr;
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t tile_capacity = 0;
+    bool order_ready = false;           // d_tile_order holds the order made from the last frame
+    int32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // width, height, strip_rows, strip_count, strip_index, tiles it was made for
+    // choice between the pooled and the single kernel by measurement (see rt_render_frame)
+    int32_t scene_generation = 0;
+    int32_t tune_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int tune_stage = 0;       // 0: first pooled frame (no tile order yet), 1: pooled, timed, 2: single, timed, 3: decided
+    float tune_pooled_ms = 0.0f;
+    int tune_choice = RT_PIPELINE_POOLED;
 
     // path state of the staged pipeline (allocated on first use, grown when needed)
     void* d_pool = nullptr;
@@ -230,6 +242,8 @@ int rt_destroy(RtContext* c) {
     free_framebuffer(c);
     free_pool(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -303,6 +317,7 @@ int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, co
     c->bvh_nodes = (int32_t)bvh.nodes.size();
     c->bvh_depth = bvh.depth;
     c->has_scene = true;
+    c->scene_generation++;
     return RT_OK;
 }
 
@@ -410,8 +425,9 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         }
     }
     fa.owned_rows = owned;
-    fa.tiles_x = (c->width + 7) / 8;
-    fa.total_slots = (uint32_t)fa.tiles_x * (uint32_t)((owned + 7) / 8) * 64u;
+    const int block_px = 1 << rtd::kBlockPixLog2;
+    fa.tiles_x = (c->width + block_px - 1) / block_px;
+    fa.total_slots = ((uint32_t)fa.tiles_x * (uint32_t)((owned + block_px - 1) / block_px)) << rtd::kBlockSlotsLog2;
     fa.flags = p.flags;
     fa.exit_quota_pct = 75;
     if (const char* q = getenv("RT_EXIT_QUOTA_PCT")) {  // tuning aid
@@ -426,13 +442,47 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     fa.primary_ids = nullptr;
     fa.path_hash = nullptr;
     fa.counters = c->d_counters;
+    fa.tile_order = nullptr;
+    fa.tile_cost = nullptr;
 
     RT_HIP(c, hipSetDevice(c->device));
+    // Tile order: each frame records what its tiles cost, and the next frame of the same size
+    // and partition hands the dear tiles out first (same pixels, same results, shorter tail).
+    const uint32_t n_tiles = fa.total_slots >> rtd::kBlockSlotsLog2;  // blocks, the unit of the order
+    const bool feedback = !(p.flags & RT_FLAG_FIXED_TILE_ORDER) && n_tiles > 0;
+    if (feedback) {
+        const int32_t key[6] = {fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index, (int32_t)n_tiles};
+        if (n_tiles > c->tile_capacity) {
+            if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+            if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+            c->d_tile_order = c->d_tile_cost = nullptr;
+            c->tile_capacity = 0;
+            c->order_ready = false;
+            RT_HIP(c, hipMalloc((void**)&c->d_tile_order, (size_t)n_tiles * 4));
+            RT_HIP(c, hipMalloc((void**)&c->d_tile_cost, (size_t)n_tiles * 4));
+            c->tile_capacity = n_tiles;
+        }
+        if (!c->order_ready || memcmp(key, c->order_key, sizeof key) != 0) {
+            c->order_ready = false;
+            memcpy(c->order_key, key, sizeof key);
+            RT_HIP(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)n_tiles * 4, c->stream));
+        }
+        fa.tile_cost = c->d_tile_cost;
+        if (c->order_ready) fa.tile_order = c->d_tile_order;
+    }
     if (p.flags & (RT_FLAG_PRIMARY_IDS | RT_FLAG_PATH_HASH)) {
         int rc = alloc_debug_buffers(c);
         if (rc != RT_OK) return rc;
         if (p.flags & RT_FLAG_PRIMARY_IDS) fa.primary_ids = c->d_primary_ids;
         if (p.flags & RT_FLAG_PATH_HASH) fa.path_hash = c->d_path_hash;
+    }
+    // kernel time of the previous frame while its events are still intact: needed when that frame
+    // was one of the timed trials of the pipeline choice below
+    float prev_ms = -1.0f;
+    if (c->timed && (c->tune_stage == 2 || c->tune_stage == 3)) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(c->ev_end) == hipSuccess && hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess)
+            prev_ms = ms;
     }
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
     RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 152, c->stream));
@@ -452,8 +502,24 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         else if (p.flags & RT_FLAG_WAVEFRONT) pipeline = RT_PIPELINE_STAGED;
         else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits) {
             RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
-            if ((unsigned long long)fa.total_slots >= (unsigned long long)grid * (unsigned long long)rtd::pool_slots_per_block())
-                pipeline = RT_PIPELINE_POOLED;
+            if ((unsigned long long)fa.total_slots >= (unsigned long long)grid * (unsigned long long)rtd::pool_slots_per_block()) {
+                // Both kernels fit this frame and neither wins everywhere (the pooled one on short
+                // frames with long paths, the single one on big scenes): the first frames of a
+                // configuration time one after the other, the rest use the faster.
+                const int32_t key[9] = {c->scene_generation, fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index,
+                                        p.spp, p.max_bounces, feedback ? 1 : 0};
+                if (memcmp(key, c->tune_key, sizeof key) != 0) {
+                    memcpy(c->tune_key, key, sizeof key);
+                    c->tune_stage = 0;
+                }
+                if (prev_ms >= 0.0f && c->tune_stage == 2) c->tune_pooled_ms = prev_ms;
+                if (prev_ms >= 0.0f && c->tune_stage == 3)
+                    c->tune_choice = (prev_ms < c->tune_pooled_ms) ? RT_PIPELINE_SINGLE : RT_PIPELINE_POOLED;
+                if (c->tune_stage <= 1) pipeline = RT_PIPELINE_POOLED;
+                else if (c->tune_stage == 2) pipeline = RT_PIPELINE_SINGLE;
+                else pipeline = c->tune_choice;
+                if (c->tune_stage < 4) c->tune_stage++;
+            }
         }
         c->last_pipeline = pipeline;
         if (pipeline == RT_PIPELINE_POOLED) {
@@ -492,6 +558,15 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
     c->timed = true;
+    if (feedback && fa.total_slots > 0) {
+        int classes = 16;
+        if (const char* q = getenv("RT_TILE_CLASSES")) {  // tuning aid
+            int v = atoi(q);
+            if (v >= 1 && v <= 64) classes = v;
+        }
+        RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, classes, c->stream));
+        c->order_ready = true;
+    }
     return RT_OK;
 }
 

@@ -273,6 +273,23 @@ def test_pipeline_ragged_sizes_and_strips(ctx, star, pipeline, size):
         assert_identical(b, a)
 
 
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
+@pytest.mark.parametrize("strip", [(0, 1, 0), (3, 2, 1)])
+def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, strip):
+    """From the second frame of a configuration on, the 8x8 tiles are handed out dearest first as
+    measured on the frame before; RT_FLAG_FIXED_TILE_ORDER keeps image order.  Three accumulated
+    frames of a ragged size, whole and as one rank's strips, must not differ by a bit."""
+    from helpers import DEBUG_FLAGS
+    W, H = 130, 37
+    fl = DEBUG_FLAGS | PIPELINES[pipeline]
+    a = gpu_frames(ctx, teapot, W, H, spp=2, max_bounces=4, frames=3, accel=capi.RT_ACCEL_BVH, strip=strip,
+                   flags=fl | capi.RT_FLAG_FIXED_TILE_ORDER)
+    b = gpu_frames(ctx, teapot, W, H, spp=2, max_bounces=4, frames=3, accel=capi.RT_ACCEL_BVH, strip=strip, flags=fl)
+    assert_identical(b, a)
+    owned = a["counts"] > 0
+    assert owned.any() and (a["counts"][owned] == 3).all()
+
+
 @pytest.mark.parametrize("workload", ["c2", "c3"])
 def test_full_size_frames_agree_across_pipelines(ctx, workload):
     """BASELINE.json's full sizes (1920x1080; C2: 4 spp x 20 bounces on the star scene, C3: 16 spp
@@ -289,12 +306,21 @@ def test_full_size_frames_agree_across_pipelines(ctx, workload):
     b = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
     assert_identical(b, a)
     assert a["stats"].pipeline == capi.RT_PIPELINE_SINGLE and b["stats"].pipeline == capi.RT_PIPELINE_POOLED
-    # the library's own choice at this size is the pooled schedule, and without the hash its light
-    # queries are bounded: still the same image
-    d = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=0)
-    assert d["stats"].pipeline == capi.RT_PIPELINE_POOLED
-    assert bit_equal_pixels(d["accum"], a["accum"]).all() and np.array_equal(d["bgra"], a["bgra"])
-    assert d["total_rays"] == a["total_rays"]
+    # left to itself the library starts a configuration on the pooled schedule, times it against the
+    # single kernel on the third frame and keeps the faster (and without the hash the light queries
+    # are bounded): five such frames, whatever ran them, are the five frames of the single kernel
+    a5 = gpu_frames(ctx, s, W, H, spp, mb, frames=5, accel=capi.RT_ACCEL_BVH, camera=cam, flags=capi.RT_FLAG_SINGLE_KERNEL)
+    ctx.upload_scene(s)
+    ctx.resize(W, H)
+    used = []
+    for f in range(5):
+        ctx.render_frame(cam, s.push_constants(0.0, f, f == 0), make_params(spp, mb, capi.RT_ACCEL_BVH))
+        used.append(ctx.stats().pipeline)
+    assert used[:3] == [capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_SINGLE]
+    assert used[3] == used[4] and used[3] in (capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_SINGLE)
+    acc, cnt = ctx.read_accum()
+    assert bit_equal_pixels(acc, a5["accum"]).all() and np.array_equal(ctx.read_bgra8(), a5["bgra"])
+    assert (cnt == 5).all()
     assert (a["counts"] == 2).all()
     assert np.isfinite(a["accum"]).all()
     # every pixel's BGRA8 byte is the rounded mean of its accumulated colour (raytracer.comp:992-995)

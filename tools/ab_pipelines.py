@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Alternate the single and the pooled pipeline on one device, same frames, and print the median
-kernel time of each.  python tools/ab_pipelines.py [c3|c2|c5] [rounds]"""
+kernel time of each.  python tools/ab_pipelines.py [c3|c2|c5] [rounds] [width height]"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import capi
@@ -9,6 +9,8 @@ from raytracer_amd.workloads import WORKLOADS, workload_camera
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
+if len(sys.argv) > 4:
+    FW, FH = int(sys.argv[3]), int(sys.argv[4])
 s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
 ms = {"single": [], "pooled": []}
@@ -20,4 +22,4 @@ for r in range(rounds + 2):
         if r >= 2:
             ms[label].append(ctx.stats().kernel_ms)
 for k, v in ms.items():
-    print(f"{name} {k}: median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
+    print(f"{name} {FW}x{FH} {k}: median {statistics.median(v):.3f} ms  min {min(v):.3f}  max {max(v):.3f}")
