@@ -12,8 +12,10 @@ for wl in c2 c5; do timeout -k 10 300 python bench.py --workload $wl --no-cpu-ba
 timeout -k 10 300 python bench.py --workload c4 --no-cpu-baseline --steps 2 --warmup 1 > $out/bench_c4.json 2> $out/bench_c4.err || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_c3 --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/prof_c3.log 2>&1 || exit 1
 cp $out/prof_c3/*/*kernel_stats.csv $out/c3_kernel_stats.csv
-BENCH_ARGS="" bash tools/pmc_passes.sh $out/pmc_c3 || exit 1
-python3 tools/pmc_summary.py $out/pmc_c3 "kernel<1, false>" > $out/c3_pmc.txt
-BENCH_ARGS="--workload c5" bash tools/pmc_passes.sh $out/pmc_c5 || exit 1
-python3 tools/pmc_summary.py $out/pmc_c5 "kernel<1, false>" > $out/c5_pmc.txt
+BENCH_ARGS="--pipeline single" bash tools/pmc_passes.sh $out/pmc_c3_single || exit 1
+python3 tools/pmc_summary.py $out/pmc_c3_single "render_kernel<1, false>" 1 > $out/c3_single_pmc.txt
+BENCH_ARGS="--pipeline pooled" bash tools/pmc_passes.sh $out/pmc_c3_pooled || exit 1
+python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<1, false>" 1 > $out/c3_pooled_pmc.txt
+BENCH_ARGS="--workload c5 --pipeline single" bash tools/pmc_passes.sh $out/pmc_c5_single || exit 1
+python3 tools/pmc_summary.py $out/pmc_c5_single "render_kernel<1, false>" 1 > $out/c5_single_pmc.txt
 cat $out/bench_c3.json; head -3 $out/c3_kernel_stats.csv
