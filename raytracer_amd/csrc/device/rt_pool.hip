@@ -1,5 +1,5 @@
 // rt_pool.hip — the pooled form of the path tracer for gfx950 (MI355X): one persistent
-// launch per frame in which every workgroup owns a pool of kPool path slots (two per lane),
+// launch per frame in which every workgroup owns a pool of kPool path slots (1408 for its 1024 lanes),
 // keeps their hot state in LDS and regroups them continuously through queues in LDS.
 //
 // One frame = one execution of shaders/raytracer.comp::main for every pixel this context
@@ -11,7 +11,7 @@
 // Why: with one path per lane (rt_kernels.hip) a wave's 64 paths disagree about what to do
 // next, and most vector instructions run with most lanes masked off; with one launch per
 // stage (rt_wavefront.hip) a 1080p frame has too few rays per launch to fill this chip.
-// Here a workgroup keeps 512 paths in flight for its 256 lanes.  Slots that wait for the
+// Here a workgroup keeps kPool paths in flight for its lanes.  Slots that wait for the
 // same kind of work queue up in LDS (search, first-bounce result, later-bounce result,
 // light-query result, sample end); a wave either
 //   * shades: pops 64 slots of ONE kind and runs that stage for all of them, or
@@ -35,18 +35,18 @@ namespace rtd {
 namespace {
 
 #ifndef RT_POOL_THREADS
-#define RT_POOL_THREADS 768
+#define RT_POOL_THREADS 1024
 #endif
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS (2 * RT_POOL_THREADS)
+#define RT_POOL_SLOTS 1408
 #endif
 #ifndef RT_POOL_STACK
 #define RT_POOL_STACK 8
 #endif
 #ifndef RT_POOL_WAVES_PER_SIMD
-#define RT_POOL_WAVES_PER_SIMD 3
+#define RT_POOL_WAVES_PER_SIMD 4
 #endif
-constexpr int kThreads = RT_POOL_THREADS;  // threads per workgroup (one workgroup per CU at 768)
+constexpr int kThreads = RT_POOL_THREADS;  // threads per workgroup: one workgroup of 16 waves per CU (128 VGPRs, 4 waves per SIMD)
 constexpr int kWaves = kThreads / 64;
 constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of kWaves, <= 4096)
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
