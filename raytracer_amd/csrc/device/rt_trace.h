@@ -167,20 +167,19 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
     // arithmetic on its infinities would report a hit
     const bool hit0 = (tmin0 <= tmax0 * 1.000001f) && (__float_as_int(q3.z) >= 0);
     const bool hit1 = (tmin1 <= tmax1 * 1.000001f) && (__float_as_int(q3.w) >= 0);
-    int r0 = __float_as_int(q3.x);
-    int r1 = __float_as_int(q3.y);
-    if (hit0 && hit1) {
-        if (tmin1 < tmin0) { int tmp = r0; r0 = r1; r1 = tmp; }
-        stack.put(tv.sp, (uint32_t)r1);
+    const int r0 = __float_as_int(q3.x);
+    const int r1 = __float_as_int(q3.y);
+    // selects around one push region and one pop region: nested branches cost more scalar
+    // instructions per visit than the selects cost vector ones
+    const bool both = hit0 && hit1;
+    const bool second_nearer = both && (tmin1 < tmin0);
+    const int near = (hit0 && !second_nearer) ? r0 : r1;
+    if (both) {
+        stack.put(tv.sp, (uint32_t)(second_nearer ? r0 : r1));
         tv.sp++;
-        tv.cur = r0;
-    } else if (hit0) {
-        tv.cur = r0;
-    } else if (hit1) {
-        tv.cur = r1;
-    } else {
-        trav_pop(tv, stack);
     }
+    if (hit0 || hit1) tv.cur = near;
+    else trav_pop(tv, stack);
 }
 
 // Test the next primitive of the leaf under the cursor.
