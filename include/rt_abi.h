@@ -270,6 +270,16 @@ int rt_scene_add_light(RtScene* s, const float pos_angle_aux[4], const float col
 int rt_scene_add_model(RtScene* s, const char* file_name, const float pos[3],
                        float pitch, float yaw, float roll, float scale, int32_t material);
 
+/* rt_scene_add_model with optional departures from the reference's loader and index handling:
+ * RT_MODEL_FULL_GLTF reads the whole default scene of the file (node transforms, every mesh and
+ * triangle primitive, byteStride, 8/16/32-bit or absent indices) instead of mesh 0 / primitive 0
+ * with tightly packed positions (loader.cpp:37-43, 76-91); RT_MODEL_REBASE_INDICES adds the
+ * model's first vertex position in the scene's vertex buffer to its indices, which addModel
+ * does not (scene.cpp:844-845), so that a scene can hold more than one model. */
+enum { RT_MODEL_FULL_GLTF = 1u, RT_MODEL_REBASE_INDICES = 2u };
+int rt_scene_add_model_ex(RtScene* s, const char* file_name, const float pos[3],
+                          float pitch, float yaw, float roll, float scale, int32_t material, uint32_t flags);
+
 typedef struct RtSceneView {  /* borrowed pointers into the RtScene, valid until it changes */
     const RtSphere* spheres;     int32_t n_spheres;    /* vector sizes (>= 1: placeholder rule) */
     const RtMaterial* materials; int32_t n_materials;

@@ -36,6 +36,7 @@ RT_FLAG_WAVEFRONT = 16
 RT_FLAG_POOLED = 32
 RT_FLAG_SINGLE_KERNEL = 64
 RT_FLAG_FIXED_TILE_ORDER = 128
+RT_MODEL_FULL_GLTF, RT_MODEL_REBASE_INDICES = 1, 2
 RT_PIPELINE_SINGLE, RT_PIPELINE_STAGED, RT_PIPELINE_POOLED = 0, 1, 2
 
 RT_SCENE_EMPTY = 0
@@ -163,6 +164,8 @@ PROTOTYPES = {
     "rt_scene_add_light": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32]),
     "rt_scene_add_model": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_int32]),
+    "rt_scene_add_model_ex": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_int32, C.c_uint32]),
     "rt_scene_view": (C.c_int, [_P, C.POINTER(RtSceneView)]),
     "rt_upload_scene_from": (C.c_int, [_P, _P]),
     "rt_camera_look": (C.c_int, [C.POINTER(RtCamera), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -7,7 +7,11 @@
 //   * POSITION read as tightly packed float3 from bufferView.byteOffset +
 //     accessor.byteOffset, byteStride ignored (loader.cpp:76-91);
 //   * node transforms, normals, UVs and materials ignored.
+// LoadModelFull is the general reader next to it: the default scene's node hierarchy with its
+// transforms, every mesh and triangle primitive, byteStride, 8/16/32-bit and absent indices,
+// indices rebased onto the concatenated vertices.
 #include "glb_loader.h"
+#include "rtm.h"
 
 #include <cstdint>
 #include <cstdio>
@@ -165,10 +169,9 @@ bool accessor_data(const JVal& root, const std::vector<unsigned char>& bin, long
     return true;
 }
 
-}  // namespace
 
-bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std::vector<uint32_t>& indices,
-               std::string* err) {
+// Reads a .glb file into its parsed JSON chunk and its BIN chunk.
+bool read_glb(const std::string& filename, JVal& root, std::vector<unsigned char>& bin, std::string* err) {
     FILE* f = fopen(filename.c_str(), "rb");
     if (!f) return fail(err, "cannot open " + filename);
     std::vector<unsigned char> file;
@@ -184,7 +187,6 @@ bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std
     if (total > file.size()) total = file.size();
 
     std::string json;
-    std::vector<unsigned char> bin;
     size_t pos = 12;
     while (pos + 8 <= total) {
         size_t len = rd32(&file[pos]);
@@ -196,10 +198,208 @@ bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std
         pos += (len + 3) & ~(size_t)3;
     }
     if (json.empty()) return fail(err, "GLB has no JSON chunk");
-
-    JVal root;
     JParser parser(json.data(), json.size());
     if (!parser.parse(root)) return fail(err, "malformed glTF JSON");
+    return true;
+}
+
+// ---- the general reader (LoadModelFull) ------------------------------------------------
+
+// An accessor resolved to its bytes: element i starts at data + i * stride.
+struct AccessorView {
+    const unsigned char* data = nullptr;
+    size_t count = 0, stride = 0;
+    long long ctype = 0;
+    std::string type;
+};
+
+size_t component_size(long long ctype) {
+    switch (ctype) {
+        case 5120: case 5121: return 1;
+        case 5122: case 5123: return 2;
+        case 5125: case 5126: return 4;
+        default: return 0;
+    }
+}
+
+bool accessor_view(const JVal& root, const std::vector<unsigned char>& bin, long long acc_idx, AccessorView& out, std::string* err) {
+    const JVal* accs = root.get("accessors");
+    const JVal* acc = (accs && acc_idx >= 0) ? accs->at((size_t)acc_idx) : nullptr;
+    if (!acc) return fail(err, "accessor index out of range");
+    if (acc->get("sparse")) return fail(err, "sparse accessors are not supported");
+    const JVal* bvi = acc->get("bufferView");
+    const JVal* bvs = root.get("bufferViews");
+    const JVal* bv = (bvi && bvs && bvi->as_int(-1) >= 0) ? bvs->at((size_t)bvi->as_int(-1)) : nullptr;
+    if (!bv) return fail(err, "accessor has no bufferView");
+    const JVal* bufi = bv->get("buffer");
+    if (!bufi || bufi->as_int(-1) != 0) return fail(err, "only the GLB-embedded buffer 0 is supported");
+    const JVal* cnt = acc->get("count");
+    const JVal* ct = acc->get("componentType");
+    const JVal* ty = acc->get("type");
+    if (!cnt || !ct || !ty || ty->kind != JVal::Str) return fail(err, "accessor lacks count/componentType/type");
+    out.count = (size_t)cnt->as_int(0);
+    out.ctype = ct->as_int(0);
+    out.type = ty->str;
+    const size_t comps = out.type == "SCALAR" ? 1 : out.type == "VEC2" ? 2 : out.type == "VEC3" ? 3 : out.type == "VEC4" ? 4 : 0;
+    const size_t csize = component_size(out.ctype);
+    if (comps == 0 || csize == 0) return fail(err, "unsupported accessor type");
+    const size_t elem = comps * csize;
+    size_t off = 0, view_len = bin.size();
+    if (const JVal* o = bv->get("byteOffset")) off = (size_t)o->as_int(0);
+    if (const JVal* o = bv->get("byteLength")) view_len = (size_t)o->as_int(0);
+    if (off > bin.size() || view_len > bin.size() - off) return fail(err, "bufferView beyond the BIN chunk");
+    size_t acc_off = 0;
+    if (const JVal* o = acc->get("byteOffset")) acc_off = (size_t)o->as_int(0);
+    out.stride = elem;
+    if (const JVal* o = bv->get("byteStride")) {
+        const long long st = o->as_int(0);
+        if (st != 0) {
+            if (st < (long long)elem) return fail(err, "byteStride smaller than the element");
+            out.stride = (size_t)st;
+        }
+    }
+    if (out.count != 0 && (acc_off > view_len || (out.count - 1) * out.stride + elem > view_len - acc_off))
+        return fail(err, "accessor data beyond its bufferView");
+    out.data = bin.data() + off + acc_off;
+    return true;
+}
+
+float rdf(const unsigned char* p) {
+    const uint32_t u = rd32(p);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Local transform of a glTF node: its `matrix` (column-major), or T * R * S from `translation`,
+// `rotation` (unit quaternion x, y, z, w) and `scale`.
+bool node_local_matrix(const JVal& node, rtm::mat4& m, std::string* err) {
+    m = rtm::identity();
+    if (const JVal* mx = node.get("matrix")) {
+        if (mx->kind != JVal::Arr || mx->arr.size() != 16) return fail(err, "node matrix must have 16 numbers");
+        float* a = &m.c[0].x;
+        for (int i = 0; i < 16; ++i) a[i] = (float)mx->arr[(size_t)i].num;
+        return true;
+    }
+    float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, sc[3] = {1, 1, 1};
+    auto read = [&](const char* key, float* dst, size_t n) -> bool {
+        const JVal* v = node.get(key);
+        if (!v) return true;
+        if (v->kind != JVal::Arr || v->arr.size() != n) return false;
+        for (size_t i = 0; i < n; ++i) dst[i] = (float)v->arr[i].num;
+        return true;
+    };
+    if (!read("translation", t, 3) || !read("rotation", q, 4) || !read("scale", sc, 3))
+        return fail(err, "malformed node translation/rotation/scale");
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    rtm::mat4 r = rtm::identity();
+    r.c[0] = {1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y + z * w), 2.0f * (x * z - y * w), 0.0f};
+    r.c[1] = {2.0f * (x * y - z * w), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z + x * w), 0.0f};
+    r.c[2] = {2.0f * (x * z + y * w), 2.0f * (y * z - x * w), 1.0f - 2.0f * (x * x + y * y), 0.0f};
+    m = rtm::mul(rtm::mul(rtm::translate(rtm::identity(), rtm::v3(t[0], t[1], t[2])), r),
+                 rtm::scale(rtm::identity(), rtm::v3(sc[0], sc[1], sc[2])));
+    return true;
+}
+
+// Appends every triangle primitive of mesh `mesh_idx`, positions transformed by `world`.
+bool append_mesh(const JVal& root, const std::vector<unsigned char>& bin, long long mesh_idx, const rtm::mat4& world,
+                 std::vector<RtVertex>& vertices, std::vector<uint32_t>& indices, std::string* err) {
+    const JVal* meshes = root.get("meshes");
+    const JVal* mesh = (meshes && mesh_idx >= 0) ? meshes->at((size_t)mesh_idx) : nullptr;
+    if (!mesh) return fail(err, "mesh index out of range");
+    const JVal* prims = mesh->get("primitives");
+    if (!prims || prims->kind != JVal::Arr) return fail(err, "mesh without primitives");
+    for (const JVal& prim : prims->arr) {
+        const JVal* mode = prim.get("mode");
+        if (mode && mode->as_int(4) != 4) continue;  // points, lines, strips and fans carry no triangle list
+        const JVal* attrs = prim.get("attributes");
+        const JVal* posacc = attrs ? attrs->get("POSITION") : nullptr;
+        if (!posacc) return fail(err, "Primitive has no POSITION attribute");
+        AccessorView pv;
+        if (!accessor_view(root, bin, posacc->as_int(-1), pv, err)) return false;
+        if (pv.type != "VEC3" || pv.ctype != 5126) return fail(err, "POSITION must be float VEC3");
+        if (vertices.size() + pv.count >= (size_t)0xffffffffu) return fail(err, "too many vertices");
+        const uint32_t base = (uint32_t)vertices.size();
+        for (size_t i = 0; i < pv.count; ++i) {
+            const unsigned char* e = pv.data + i * pv.stride;
+            const rtm::vec4 p = rtm::mul(world, rtm::v4(rdf(e), rdf(e + 4), rdf(e + 8), 1.0f));
+            RtVertex v;
+            v.pos[0] = p.x; v.pos[1] = p.y; v.pos[2] = p.z;
+            v._pad = 0.0f;
+            vertices.push_back(v);
+        }
+        const JVal* idx = prim.get("indices");
+        if (!idx || idx->as_int(-1) < 0) {  // non-indexed: consecutive triples
+            for (size_t i = 0; i + 3 <= pv.count; i += 3)
+                for (uint32_t k = 0; k < 3; ++k) indices.push_back(base + (uint32_t)i + k);
+            continue;
+        }
+        AccessorView iv;
+        if (!accessor_view(root, bin, idx->as_int(-1), iv, err)) return false;
+        if (iv.type != "SCALAR" || (iv.ctype != 5121 && iv.ctype != 5123 && iv.ctype != 5125))
+            return fail(err, "Unsupported index component type");
+        for (size_t i = 0; i < iv.count; ++i) {
+            const unsigned char* e = iv.data + i * iv.stride;
+            const uint32_t v = iv.ctype == 5121 ? (uint32_t)e[0] : iv.ctype == 5123 ? ((uint32_t)e[0] | ((uint32_t)e[1] << 8)) : rd32(e);
+            if (v >= pv.count) return fail(err, "index beyond the primitive's vertices");
+            indices.push_back(base + v);
+        }
+    }
+    return true;
+}
+
+bool append_node(const JVal& root, const std::vector<unsigned char>& bin, long long node_idx, const rtm::mat4& parent, int depth,
+                 std::vector<RtVertex>& vertices, std::vector<uint32_t>& indices, std::string* err) {
+    if (depth > 64) return fail(err, "node hierarchy deeper than 64 (cycle?)");
+    const JVal* nodes = root.get("nodes");
+    const JVal* node = (nodes && node_idx >= 0) ? nodes->at((size_t)node_idx) : nullptr;
+    if (!node) return fail(err, "node index out of range");
+    rtm::mat4 local;
+    if (!node_local_matrix(*node, local, err)) return false;
+    const rtm::mat4 world = rtm::mul(parent, local);
+    if (const JVal* m = node->get("mesh"))
+        if (!append_mesh(root, bin, m->as_int(-1), world, vertices, indices, err)) return false;
+    if (const JVal* ch = node->get("children")) {
+        if (ch->kind != JVal::Arr) return fail(err, "malformed node children");
+        for (const JVal& c : ch->arr)
+            if (!append_node(root, bin, c.as_int(-1), world, depth + 1, vertices, indices, err)) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool LoadModelFull(const std::string& filename, std::vector<RtVertex>& vertices, std::vector<uint32_t>& indices,
+                   std::string* err) {
+    JVal root;
+    std::vector<unsigned char> bin;
+    if (!read_glb(filename, root, bin, err)) return false;
+    vertices.clear();
+    indices.clear();
+    const JVal* scenes = root.get("scenes");
+    if (scenes && scenes->kind == JVal::Arr && !scenes->arr.empty()) {
+        long long which = 0;
+        if (const JVal* s = root.get("scene")) which = s->as_int(0);
+        const JVal* scene = scenes->at((size_t)which);
+        const JVal* roots = scene ? scene->get("nodes") : nullptr;
+        if (!roots || roots->kind != JVal::Arr) return fail(err, "scene without nodes");
+        for (const JVal& n : roots->arr)
+            if (!append_node(root, bin, n.as_int(-1), rtm::identity(), 0, vertices, indices, err)) return false;
+    } else {  // no scene graph: every mesh where it stands
+        const JVal* meshes = root.get("meshes");
+        if (!meshes || meshes->kind != JVal::Arr) return fail(err, "No meshes found in GLTF file");
+        for (size_t m = 0; m < meshes->arr.size(); ++m)
+            if (!append_mesh(root, bin, (long long)m, rtm::identity(), vertices, indices, err)) return false;
+    }
+    if (indices.empty()) return fail(err, "no triangles found in " + filename);
+    return true;
+}
+
+bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std::vector<uint32_t>& indices,
+               std::string* err) {
+    JVal root;
+    std::vector<unsigned char> bin;
+    if (!read_glb(filename, root, bin, err)) return false;
 
     const JVal* meshes = root.get("meshes");
     if (!meshes || meshes->kind != JVal::Arr || meshes->arr.empty()) return fail(err, "No meshes found in GLTF file");

@@ -100,6 +100,14 @@ int rt_scene_add_model(RtScene* s, const char* file_name, const float pos[3], fl
     return s->scene.addModel(m) ? RT_OK : RT_ERR_IO;
 }
 
+int rt_scene_add_model_ex(RtScene* s, const char* file_name, const float pos[3], float pitch, float yaw, float roll,
+                          float scale, int32_t material, uint32_t flags) {
+    if (!s || !file_name || !pos || !mat_ok(s->scene, material)) return RT_ERR_INVALID_ARGUMENT;
+    if (flags & ~(uint32_t)(RT_MODEL_FULL_GLTF | RT_MODEL_REBASE_INDICES)) return RT_ERR_INVALID_ARGUMENT;
+    rt::Model m{file_name, rtm::v3(pos[0], pos[1], pos[2]), pitch, yaw, roll, scale, material};
+    return s->scene.addModelEx(m, flags) ? RT_OK : RT_ERR_IO;
+}
+
 int rt_scene_view(const RtScene* s, RtSceneView* out) {
     if (!s || !out) return RT_ERR_INVALID_ARGUMENT;
     const Scene& sc = s->scene;

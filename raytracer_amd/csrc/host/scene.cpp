@@ -166,7 +166,12 @@ void Scene::addQuad(const Quad& q) {
 
 // scene.cpp:801-846.  A load failure is reported and the model is recorded as an empty
 // mesh, as in the reference (812-814); the return value additionally tells the caller.
-bool Scene::addModel(const Model& model) {
+bool Scene::addModel(const Model& model) { return addModelEx(model, 0u); }
+
+// addModel with two optional departures from the reference (flags = RT_MODEL_*): the general GLB
+// reader instead of the mesh-0 / primitive-0 one, and indices rebased onto this model's vertices
+// so that several models can share the vertex buffer.
+bool Scene::addModelEx(const Model& model, unsigned flags) {
     if (total_meshes == 0) {
         meshVec.pop_back();
         vertexVec.pop_back();
@@ -175,7 +180,8 @@ bool Scene::addModel(const Model& model) {
     std::vector<RtVertex> vs;
     std::vector<uint32_t> is;
     std::string err;
-    bool ok = LoadModel(assets_dir + model.file_name, vs, is, &err);
+    bool ok = (flags & RT_MODEL_FULL_GLTF) ? LoadModelFull(assets_dir + model.file_name, vs, is, &err)
+                                           : LoadModel(assets_dir + model.file_name, vs, is, &err);
     if (!ok) {
         last_error = "Error loading model " + assets_dir + model.file_name + ": " + err;
         fprintf(stderr, "%s\n", last_error.c_str());
@@ -195,8 +201,11 @@ bool Scene::addModel(const Model& model) {
     total_meshes = (int)meshVec.size();
 
     // Indices are appended as loaded (mesh-local), exactly like scene.cpp:844-845: a second
-    // model's indices are NOT rebased onto its vertices.  Use one model per scene, or
-    // createTeapotGrid-style baking, when that matters.
+    // model's indices are NOT rebased onto its vertices, unless RT_MODEL_REBASE_INDICES asks for it.
+    if (flags & RT_MODEL_REBASE_INDICES) {
+        const uint32_t base = (uint32_t)vertexVec.size();
+        for (uint32_t& i : is) i += base;
+    }
     vertexVec.insert(vertexVec.end(), vs.begin(), vs.end());
     indexVec.insert(indexVec.end(), is.begin(), is.end());
     return ok;

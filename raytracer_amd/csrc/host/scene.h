@@ -60,6 +60,7 @@ public:
     void addTriangle(RtTriangle t);
     void addQuad(const Quad& q);
     bool addModel(const Model& model);
+    bool addModelEx(const Model& model, unsigned flags);  // flags: RT_MODEL_* (rt_abi.h)
     void printSceneInfo() const;
 
 private:

@@ -79,7 +79,13 @@ class Scene:
         self._chk(self._lib.rt_scene_add_light(self._h, _f4(pos_angle_aux), _f4(color_str), int(light_type)),
                   "rt_scene_add_light")
 
-    def add_model(self, file_name, pos, pitch, yaw, roll, scale, material):
+    def add_model(self, file_name, pos, pitch, yaw, roll, scale, material, flags: int = 0):
+        """Scene::addModel; `flags` (capi.RT_MODEL_*) select the general GLB reader and index rebasing."""
+        if flags:
+            self._chk(self._lib.rt_scene_add_model_ex(self._h, file_name.encode(), _f3(pos), float(pitch), float(yaw),
+                                                      float(roll), float(scale), int(material), int(flags)),
+                      "rt_scene_add_model_ex")
+            return
         self._chk(self._lib.rt_scene_add_model(self._h, file_name.encode(), _f3(pos), float(pitch), float(yaw),
                                                float(roll), float(scale), int(material)), "rt_scene_add_model")
 

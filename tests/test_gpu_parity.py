@@ -156,6 +156,27 @@ def test_light_types_transparency_and_transmission(ctx, kind, accel):
     assert np.isfinite(g["accum"]).all()
 
 
+@pytest.mark.parametrize("accel", [capi.RT_ACCEL_FLAT, capi.RT_ACCEL_BVH])
+def test_scene_with_two_rebased_models(ctx, accel):
+    """Two models in one scene (general GLB reader, indices rebased onto each model's vertices - the
+    case scene.cpp:844-845 cannot express): the mesh path of the search against the oracle."""
+    s = _custom_scene("directional")
+    gold = s.add_material((1.0, 0.78, 0.34, 1), (0, 0, 0, 0), (1, 1, 1, 0.5), (0, 0, 0, 0), 0.2, 1.0, 1.5, 0.0)
+    fl = capi.RT_MODEL_FULL_GLTF | capi.RT_MODEL_REBASE_INDICES
+    s.add_model("star.glb", (1.0, 2.5, 1.0), 0.0, 20.0, 180.0, 0.1, gold, flags=fl)
+    s.add_model("teapot.glb", (4.0, 1.5, 0.5), 90.0, 30.0, 0.0, 0.3, gold, flags=fl)
+    assert s.view().total_meshes == 2
+    W, H = 96, 54
+    o = oracle_frames(s, W, H, spp=2, max_bounces=4)
+    g = gpu_frames(ctx, s, W, H, spp=2, max_bounces=4, accel=accel)
+    if accel == capi.RT_ACCEL_FLAT:
+        assert_identical(g, o)
+    else:
+        assert_identical_but_edge_ties(g, o)
+    n_prims = s.bvh_info()["prims"]
+    assert (g["primary_ids"] >= n_prims - 6320).any()  # the second model is seen: its ids are the last 6320
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (9, 17), (130, 5)])
 def test_ragged_image_sizes(ctx, star, size):
     """Sizes that are not multiples of the 8x8 pixel tiles: every pixel written exactly once."""
