@@ -1,4 +1,4 @@
-"""The benchmark configurations of BASELINE.json (C2..C5), shared by bench.py and tools/."""
+"""The configurations of BASELINE.json (C1..C5), shared by bench.py, the tests and tools/."""
 from __future__ import annotations
 
 from . import capi
@@ -6,6 +6,8 @@ from .renderer import default_camera, look_camera
 
 # name: (scene preset, width, height, spp, max_bounces, description)
 WORKLOADS = {
+    "c1": (capi.RT_SCENE_CORNELL_TEAPOT, 640, 360, 1, 1,
+           "Cornell box + teapot.glb (6360 primitives), 640x360, 1 spp, primary + 1 bounce (the CPU-runnable case)"),
     "c2": (capi.RT_SCENE_CORNELL_STAR, 1920, 1080, 4, 20,
            "reference default scene (Cornell box + star.glb, 100 primitives), 1920x1080, 4 spp, 20 bounces"),
     "c3": (capi.RT_SCENE_CORNELL_TEAPOT, 1920, 1080, 16, 4,

@@ -294,6 +294,20 @@ def test_pipeline_ragged_sizes_and_strips(ctx, star, pipeline, size):
         assert_identical(b, a)
 
 
+def test_c1_at_full_size_against_the_oracle(ctx, teapot):
+    """BASELINE.json's CPU-runnable configuration in full: Cornell box + teapot.glb, 640x360, 1 spp,
+    primary + 1 bounce.  Flat search (the reference's algorithm): every output bit-identical to the
+    oracle; BVH search: the same but for documented edge-tie pixels."""
+    from raytracer_amd.workloads import WORKLOADS
+    _, W, H, spp, mb, _ = WORKLOADS["c1"]
+    o = oracle_frames(teapot, W, H, spp=spp, max_bounces=mb, threads=16)
+    g = gpu_frames(ctx, teapot, W, H, spp=spp, max_bounces=mb, accel=capi.RT_ACCEL_FLAT)
+    assert_identical(g, o)
+    b = gpu_frames(ctx, teapot, W, H, spp=spp, max_bounces=mb, accel=capi.RT_ACCEL_BVH)
+    assert_identical_but_edge_ties(b, o)
+    assert (o["primary_ids"] >= 0).mean() > 0.3  # the box fills a good part of the frame
+
+
 @pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 @pytest.mark.parametrize("strip", [(0, 1, 0), (3, 2, 1)])
 def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, strip):
