@@ -67,12 +67,24 @@ struct PoolLds {
     int32_t hit_idx[kPool];
     // queues
     uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
-    uint32_t count[kQueues];         // entries published and not yet claimed
-    uint32_t head[kQueues];          // next ring position to pop
+    // What every wave polls once per round, in one 32-byte block (two 16-byte LDS reads):
+    // hc[q] = next ring position to pop << 16 | entries published and not yet claimed (one word, so
+    // that a pop claims entries and advances the position with a single compare-and-swap);
+    // live = slots that still carry a pixel; abort = a bound on waiting was exceeded (never in a
+    // correct run).
+    alignas(16) uint32_t hc[kQueues];
+    uint32_t live;
+    uint32_t abort;
+    uint32_t ctl_pad;
     uint32_t tail[kQueues];          // next ring position to push
-    uint32_t live;                   // slots that still carry a pixel
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
-    uint32_t abort;                  // set when a bound on waiting was exceeded (never in a correct run)
+};
+static_assert(kQueues == 5 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+struct PoolCtl {
+    uint32_t count[kQueues], live, abort;
 };
 
 // Accessor of slot i: hot fields in LDS, cold record (4 float4: pixel sum, pixel cost | normal, s_d |
@@ -123,6 +135,18 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 RT_DEV uint32_t lds_peek(const uint32_t* p) { return *(const volatile lds_u32*)p; }
 RT_DEV void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
 
+// One coherent look at the queues' fill, the live count and the abort flag.
+RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
+    const u32x4 a = *(const volatile lds_u32x4*)&L.hc[0];
+    const u32x4 b = *(const volatile lds_u32x4*)&L.hc[4];
+    PoolCtl c;
+    c.count[0] = a.x & 0xffffu; c.count[1] = a.y & 0xffffu; c.count[2] = a.z & 0xffffu; c.count[3] = a.w & 0xffffu;
+    c.count[4] = b.x & 0xffffu;
+    c.live = b.y;
+    c.abort = b.z;
+    return c;
+}
+
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
 // LDS and device memory) is visible to the workgroup before the entries can be claimed.
 RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
@@ -135,7 +159,27 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader);
     if (want) *(volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane_id() == leader) atomicAdd(&L.count[q], n);
+    if (lane_id() == leader) atomicAdd(&L.hc[q], n);
+}
+
+// The same for the three result queues at once (kind 0..2 = Q_FIRST, Q_NEXT, Q_LIGHT; -1: the lane
+// has nothing): lanes 0..2 reserve for one queue each, so the wave pays one LDS atomic round trip.
+RT_DEV void queue_push_results(PoolLds& L, int kind, uint32_t item) {
+    const unsigned long long m0 = __ballot(kind == 0), m1 = __ballot(kind == 1), m2 = __ballot(kind == 2);
+    if ((m0 | m1 | m2) == 0ull) return;
+    const int lane = lane_id();
+    const uint32_t n_mine = lane == 0 ? (uint32_t)__popcll(m0) : lane == 1 ? (uint32_t)__popcll(m1) : lane == 2 ? (uint32_t)__popcll(m2) : 0u;
+    uint32_t pos = 0;
+    if (lane < 3 && n_mine != 0u) pos = atomicAdd(&L.tail[Q_FIRST + lane], n_mine);
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 0), p1 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 1),
+                   p2 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 2);
+    if (kind >= 0) {
+        const unsigned long long mk = kind == 0 ? m0 : kind == 1 ? m1 : m2;
+        const uint32_t base = kind == 0 ? p0 : kind == 1 ? p1 : p2;
+        *(volatile lds_u16*)&L.items[Q_FIRST + kind][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane < 3 && n_mine != 0u) atomicAdd(&L.hc[Q_FIRST + lane], n_mine);
 }
 
 // Claim up to one entry for each lane of `takers` (in lane order), but nothing if fewer than
@@ -146,14 +190,15 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     const uint32_t want = (uint32_t)__popcll(takers);
     uint32_t n = 0, pos = 0;
     if (want != 0u && lane_id() == 0) {
-        uint32_t c = lds_peek(&L.count[q]);
-        while (c != 0u && c >= at_least) {
+        uint32_t w = lds_peek(&L.hc[q]);
+        for (;;) {
+            const uint32_t c = w & 0xffffu;
+            if (c == 0u || c < at_least) break;
             const uint32_t take = c < want ? c : want;
-            const uint32_t old = atomicCAS(&L.count[q], c, c - take);
-            if (old == c) { n = take; break; }
-            c = old;
+            const uint32_t old = atomicCAS(&L.hc[q], w, (((w >> 16) + take) << 16) | (c - take));
+            if (old == w) { n = take; pos = w >> 16; break; }
+            w = old;
         }
-        if (n != 0u) pos = atomicAdd(&L.head[q], n);
     }
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
     pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
@@ -238,8 +283,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow), kShortStack, kThreads};
 
     for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
-    if (tid < kQueues) { L.count[tid] = 0; L.head[tid] = 0; L.tail[tid] = 0; }
-    if (tid == 0) { L.live = kPool; L.abort = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    if (tid < kQueues) { L.hc[tid] = 0; L.tail[tid] = 0; }
+    if (tid == 0) { L.live = kPool; L.abort = 0; L.ctl_pad = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (int g = 0; g * 64 < kPool / kWaves; ++g)
         take_pixels(L, fa, cold_base, g * 64 + lane < kPool / kWaves, (uint32_t)(wave * (kPool / kWaves) + g * 64 + lane));
@@ -260,21 +305,22 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const unsigned long long t_begin = STATS ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
-        if (lds_peek(&L.abort) != 0u) break;
+        const PoolCtl ctl = poll_ctl(L);
+        if (ctl.abort != 0u) break;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
-        const uint32_t c_first = lds_peek(&L.count[Q_FIRST]), c_next = lds_peek(&L.count[Q_NEXT]);
-        const uint32_t c_light = lds_peek(&L.count[Q_LIGHT]), c_end = lds_peek(&L.count[Q_END]);
+        const uint32_t c_first = ctl.count[Q_FIRST], c_next = ctl.count[Q_NEXT];
+        const uint32_t c_light = ctl.count[Q_LIGHT], c_end = ctl.count[Q_END];
         int q = Q_LIGHT;
         uint32_t best = c_light;
         if (c_next > best) { best = c_next; q = Q_NEXT; }
         if (c_first > best) { best = c_first; q = Q_FIRST; }
         if (c_end > best) { best = c_end; q = Q_END; }
         const unsigned long long busy = __ballot(slot >= 0);
-        const bool nothing_to_search = (busy == 0ull) && lds_peek(&L.count[Q_SEARCH]) == 0u;
+        const bool nothing_to_search = (busy == 0ull) && ctl.count[Q_SEARCH] == 0u;
         // a job is worth a wave when it is full; when the pool runs thin (end of the frame, or fewer
         // pixels than slots) a sixteenth of the live paths must do, or they would wait for each other
-        uint32_t job_thresh = lds_peek(&L.live) >> 4;
+        uint32_t job_thresh = ctl.live >> 4;
         job_thresh = job_thresh < 1u ? 1u : (job_thresh > (uint32_t)job_min ? (uint32_t)job_min : job_thresh);
         if (best >= job_thresh || (nothing_to_search && best != 0u)) {
             uint32_t item = 0;
@@ -316,9 +362,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 L.hit_t[slot] = tv.best_t;
                 L.hit_idx[slot] = tv.best_idx;
             }
-            queue_push(L, Q_FIRST, mine && skind == 0, (uint32_t)slot);
-            queue_push(L, Q_NEXT, mine && skind == 1, (uint32_t)slot);
-            queue_push(L, Q_LIGHT, mine && skind == 2, (uint32_t)slot);  // entry kind bits 0 = searched
+            queue_push_results(L, mine ? skind : -1, (uint32_t)slot);  // to Q_FIRST / Q_NEXT / Q_LIGHT (entry kind bits 0 = searched)
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
