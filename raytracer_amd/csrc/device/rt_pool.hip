@@ -162,24 +162,31 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     if (lane_id() == leader) atomicAdd(&L.hc[q], n);
 }
 
-// The same for the three result queues at once (kind 0..2 = Q_FIRST, Q_NEXT, Q_LIGHT; -1: the lane
-// has nothing): lanes 0..2 reserve for one queue each, so the wave pays one LDS atomic round trip.
-RT_DEV void queue_push_results(PoolLds& L, int kind, uint32_t item) {
-    const unsigned long long m0 = __ballot(kind == 0), m1 = __ballot(kind == 1), m2 = __ballot(kind == 2);
-    if ((m0 | m1 | m2) == 0ull) return;
-    const int lane = lane_id();
-    const uint32_t n_mine = lane == 0 ? (uint32_t)__popcll(m0) : lane == 1 ? (uint32_t)__popcll(m1) : lane == 2 ? (uint32_t)__popcll(m2) : 0u;
-    uint32_t pos = 0;
-    if (lane < 3 && n_mine != 0u) pos = atomicAdd(&L.tail[Q_FIRST + lane], n_mine);
-    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 0), p1 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 1),
-                   p2 = (uint32_t)__builtin_amdgcn_readlane((int)pos, 2);
-    if (kind >= 0) {
-        const unsigned long long mk = kind == 0 ? m0 : kind == 1 ? m1 : m2;
-        const uint32_t base = kind == 0 ? p0 : kind == 1 ? p1 : p2;
-        *(volatile lds_u16*)&L.items[Q_FIRST + kind][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+// The same for several queues at once: every lane names its queue (0..kQueues-1, or -1 for
+// nothing) and its item; lanes 0..kQueues-1 reserve for one queue each, so the wave pays one LDS
+// atomic round trip however many queues receive entries.
+RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
+    unsigned long long m[kQueues];
+    unsigned long long any = 0ull;
+    for (int k = 0; k < kQueues; ++k) {
+        m[k] = __ballot(q == k);
+        any |= m[k];
     }
+    if (any == 0ull) return;
+    const int lane = lane_id();
+    uint32_t n_mine = 0;
+    for (int k = 0; k < kQueues; ++k) n_mine = (lane == k) ? (uint32_t)__popcll(m[k]) : n_mine;
+    uint32_t pos = 0;
+    if (lane < kQueues && n_mine != 0u) pos = atomicAdd(&L.tail[lane], n_mine);
+    uint32_t base = 0;
+    unsigned long long mk = 0ull;
+    for (int k = 0; k < kQueues; ++k) {
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
+        if (q == k) { base = pk; mk = m[k]; }
+    }
+    if (q >= 0) *(volatile lds_u16*)&L.items[q][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)] = (uint16_t)item;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane < 3 && n_mine != 0u) atomicAdd(&L.hc[Q_FIRST + lane], n_mine);
+    if (lane < kQueues && n_mine != 0u) atomicAdd(&L.hc[lane], n_mine);
 }
 
 // Claim up to one entry for each lane of `takers` (in lane order), but nothing if fewer than
@@ -341,13 +348,20 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 bool ends = false;
                 uint32_t next_stage = WF_IDLE;
                 if (got) ends = shade_item(sc, fa, ps, recs, q - Q_FIRST, WF_LIGHT_SEARCH + (item >> 12), next_stage);
-                const bool go = got && !ends;
-                queue_push(L, Q_END, got && ends, i);
-                queue_push(L, Q_SEARCH, go && next_stage == WF_PATH_NEXT, i | (1u << 12));
-                queue_push(L, Q_SEARCH, go && next_stage == WF_LIGHT_SEARCH, i | (2u << 12));
-                // light picked without a search: straight to the light-result stage, the case in the entry
-                queue_push(L, Q_LIGHT, go && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF,
-                           i | ((next_stage - WF_LIGHT_SEARCH) << 12));
+                // where the slot goes next: sample end, search (path ray or light query, the kind in the
+                // entry), or straight to the light-result stage when the light needs no search
+                int to = -1;
+                uint32_t entry = i;
+                if (got && ends) {
+                    to = Q_END;
+                } else if (got && next_stage == WF_PATH_NEXT) {
+                    to = Q_SEARCH; entry = i | (1u << 12);
+                } else if (got && next_stage == WF_LIGHT_SEARCH) {
+                    to = Q_SEARCH; entry = i | (2u << 12);
+                } else if (got && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF) {
+                    to = Q_LIGHT; entry = i | ((next_stage - WF_LIGHT_SEARCH) << 12);
+                }
+                queue_push_any(L, to, entry);
             }
             if (STATS) job_cycles[q - Q_FIRST] += __builtin_readcyclecounter() - t_job;
             continue;
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 L.hit_t[slot] = tv.best_t;
                 L.hit_idx[slot] = tv.best_idx;
             }
-            queue_push_results(L, mine ? skind : -1, (uint32_t)slot);  // to Q_FIRST / Q_NEXT / Q_LIGHT (entry kind bits 0 = searched)
+            queue_push_any(L, mine ? Q_FIRST + skind : -1, (uint32_t)slot);  // Q_FIRST / Q_NEXT / Q_LIGHT (entry kind bits 0 = searched)
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
