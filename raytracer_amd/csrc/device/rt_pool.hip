@@ -224,11 +224,11 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     return n;
 }
 
-// Give the asking lanes' slots their next pixel and queue them for the search.  Pixel slots
+// Give the asking lanes' slots their next pixel (the caller queues them for the search).  Pixel slots
 // of the frame come from the workgroup's reserve, refilled kChunk at a time from the frame's
 // counter (one global atomic per kChunk pixels; the reserve is handed out under a small LDS
 // lock, taken a few hundred times per frame).  A slot that finds the frame exhausted dies.
-RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool need, uint32_t local) {
+RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool need, uint32_t local) {
     bool started = false, dead = false;
     for (;;) {
         const unsigned long long m = __ballot(need);
@@ -272,9 +272,9 @@ RT_DEV void take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool
             // else: a slot of a ragged edge tile outside the image; ask again
         }
     }
-    queue_push(L, Q_SEARCH, started, local);
     const unsigned long long d = __ballot(dead);
     if (d != 0ull && lane_id() == __ffsll((long long)d) - 1) atomicSub(&L.live, (uint32_t)__popcll(d));
+    return started;  // the caller queues these slots for the search
 }
 
 template <int ACCEL, bool STATS>
@@ -294,7 +294,10 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     if (tid == 0) { L.live = kPool; L.abort = 0; L.ctl_pad = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (int g = 0; g * 64 < kPool / kWaves; ++g)
-        take_pixels(L, fa, cold_base, g * 64 + lane < kPool / kWaves, (uint32_t)(wave * (kPool / kWaves) + g * 64 + lane));
+    {
+        const uint32_t mine = (uint32_t)(wave * (kPool / kWaves) + g * 64 + lane);
+        queue_push(L, Q_SEARCH, take_pixels(L, fa, cold_base, g * 64 + lane < kPool / kWaves, mine), mine);
+    }
 
     // the ray this lane walks the BVH for
     int slot = -1;   // slot index, -1: none
@@ -342,8 +345,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             if (q == Q_END) {
                 bool alive = false;
                 if (got) end_item(fa, ps, alive);
-                queue_push(L, Q_SEARCH, got && alive, i);  // WF_PATH_FIRST
-                take_pixels(L, fa, cold_base, got && !alive, i);
+                const bool started = take_pixels(L, fa, cold_base, got && !alive, i);
+                queue_push(L, Q_SEARCH, (got && alive) || started, i);  // WF_PATH_FIRST: next sample or next pixel
             } else {
                 bool ends = false;
                 uint32_t next_stage = WF_IDLE;
