@@ -291,12 +291,15 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
 
     for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
     if (tid < kQueues) { L.hc[tid] = 0; L.tail[tid] = 0; }
-    if (tid == 0) { L.live = kPool; L.abort = 0; L.ctl_pad = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    // A frame with fewer pixels than the pools have slots is shared out evenly: every workgroup fills
+    // only its share of slots (the rest stay dead), so that all CUs get work.
+    const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
+    const uint32_t per_wave = share >= (uint32_t)kPool ? (uint32_t)(kPool / kWaves) : (share + kWaves - 1u) / kWaves;
+    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
-    for (int g = 0; g * 64 < kPool / kWaves; ++g)
-    {
-        const uint32_t mine = (uint32_t)(wave * (kPool / kWaves) + g * 64 + lane);
-        queue_push(L, Q_SEARCH, take_pixels(L, fa, cold_base, g * 64 + lane < kPool / kWaves, mine), mine);
+    for (uint32_t g = 0; g * 64u < per_wave; ++g) {
+        const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
+        queue_push(L, Q_SEARCH, take_pixels(L, fa, cold_base, g * 64u + (uint32_t)lane < per_wave, mine), mine);
     }
 
     // the ray this lane walks the BVH for
@@ -494,7 +497,8 @@ hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, u
         int v = atoi(q);
         if (v >= 1 && v < per_cu) per_cu = v;
     }
-    const long long want = ((long long)fa.total_slots + kPool - 1) / kPool, cap = (long long)cu_count * per_cu;
+    // every CU takes part as long as a workgroup gets a few waves' worth of pixels
+    const long long want = ((long long)fa.total_slots + kChunk - 1) / kChunk, cap = (long long)cu_count * per_cu;
     *grid = (unsigned)(want < cap ? want : cap);
     return hipSuccess;
 }

@@ -501,11 +501,10 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (p.flags & RT_FLAG_POOLED) pipeline = RT_PIPELINE_POOLED;
         else if (p.flags & RT_FLAG_WAVEFRONT) pipeline = RT_PIPELINE_STAGED;
         else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits) {
-            RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
-            if ((unsigned long long)fa.total_slots >= (unsigned long long)grid * (unsigned long long)rtd::pool_slots_per_block()) {
-                // Both kernels fit this frame and neither wins everywhere (the pooled one on short
-                // frames with long paths, the single one on big scenes): the first frames of a
-                // configuration time one after the other, the rest use the faster.
+            if (fa.total_slots >= 16384u) {
+                // Neither kernel wins everywhere (the pooled one on most frames, the single one on big
+                // scenes with few samples): the first frames of a configuration time one after the
+                // other, the rest use the faster.  Frames of a few thousand pixels are not worth it.
                 const int32_t key[9] = {c->scene_generation, fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index,
                                         p.spp, p.max_bounces, feedback ? 1 : 0};
                 if (memcmp(key, c->tune_key, sizeof key) != 0) {
