@@ -144,9 +144,10 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
        RT_FLAG_FIXED_TILE_ORDER = 128u /* hand the image's 8x8 tiles out in image order instead of
                                       dearest-first as measured on the previous frame of the same
                                       size; same results, only the schedule differs              */ };
-/* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: the
- * pooled pipeline when the BVH is used and the frame has at least as many pixels as the pools have
- * slots (1536 per CU), the single kernel otherwise.  All pipelines give the same bits. */
+/* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: with
+ * the BVH and at least 16384 pixels it times the pooled kernel (frame 2 of a configuration) against
+ * the single kernel (frame 3) and keeps the faster from frame 4 on; otherwise the single kernel.
+ * All pipelines give the same bits. */
 enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_STAGED = 1, RT_PIPELINE_POOLED = 2 };
 
 typedef struct RtStats {
