@@ -87,8 +87,8 @@ struct PoolCtl {
     uint32_t count[kQueues], live, abort;
 };
 
-// Accessor of slot i: hot fields in LDS, cold record (4 float4: pixel sum, pixel cost | normal, s_d |
-// path direction, light | material bits) in device memory.
+// Accessor of slot i: hot fields in LDS, cold record (pixel sum, pixel cost | normal, light distance |
+// incoming direction, packed light / material / face bits; 64-byte stride) in device memory.
 struct PoolSlot {
     PoolLds& L;
     float4* cold;
@@ -116,16 +116,17 @@ struct PoolSlot {
     // bounds of a light query's search, kept in the hit fields until the search overwrites them
     RT_DEV void put_search_bounds(float t_max, float t_occl) const { L.hit_t[i] = t_max; L.hit_idx[i] = __float_as_int(t_occl); }
     RT_DEV void put_light_query(const LightQuery& q) const {
+        // 32 bytes: normal, light distance | incoming direction, front face << 31 | light << 16 | material
+        // (the host offers this kernel only to scenes with at most 32768 lights and 65536 materials)
         cold[1] = f4(q.normal, q.s_d);
-        cold[2] = f4(q.vdir, __uint_as_float((uint32_t)q.light));
-        cold[3] = make_float4(__uint_as_float((uint32_t)q.mat | (q.front_face ? 0x80000000u : 0u)), 0.0f, 0.0f, 0.0f);
+        cold[2] = f4(q.vdir, __uint_as_float((q.front_face ? 0x80000000u : 0u) | ((uint32_t)q.light << 16) | (uint32_t)q.mat));
     }
     RT_DEV void get_light_query(LightQuery& q) const {
         const float4 n = cold[1], v = cold[2];
-        const uint32_t mbits = __float_as_uint(cold[3].x);
+        const uint32_t bits = __float_as_uint(v.w);
         q.normal = xyz(n); q.s_d = n.w;
-        q.vdir = xyz(v); q.light = (int)__float_as_uint(v.w);
-        q.mat = (int)(mbits & 0x7fffffffu); q.front_face = (mbits >> 31) != 0u;
+        q.vdir = xyz(v); q.light = (int)((bits >> 16) & 0x7fffu);
+        q.mat = (int)(bits & 0xffffu); q.front_face = (bits >> 31) != 0u;
     }
 };
 

@@ -495,7 +495,8 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
             if (v >= 1 && v <= 64) refill_min = v;
         }
         // which schedule of the per-path program runs this frame (see rt_abi.h)
-        const bool pooled_fits = p.spp <= 65535 && p.max_bounces <= 65534;  // 16-bit sample / bounce counters
+        // 16-bit sample / bounce counters in LDS; light and material index share a word of the slot record
+        const bool pooled_fits = p.spp <= 65535 && p.max_bounces <= 65534 && c->n_lights <= 32768 && c->n_materials <= 65536;
         unsigned grid = 0;
         int pipeline = RT_PIPELINE_SINGLE;
         if (p.flags & RT_FLAG_POOLED) pipeline = RT_PIPELINE_POOLED;
@@ -524,7 +525,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (pipeline == RT_PIPELINE_POOLED) {
             RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
             if (!pooled_fits)
-                return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline packs sample and bounce counters into 16 bits each");
+                return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline holds at most 65535 samples, 65534 bounces, 32768 lights and 65536 materials");
             rtd::PathPool pp;
             int rc = ensure_pooled_pool(c, grid, pp);
             if (rc != RT_OK) return rc;
