@@ -128,7 +128,12 @@ typedef struct RtParams {
     int32_t strip_count;  /* number of contexts sharing the frame (>= 1)                       */
     int32_t strip_index;  /* this context renders rows y with (y/strip_rows)%strip_count==idx  */
     uint32_t flags;       /* RT_FLAG_*                                                         */
+    int32_t skybox;       /* RT_SKY_*: which of the shader's skybox functions a missed ray sees */
 } RtParams;
+
+/* The shader's skybox variants (raytracer.comp:520-577); the reference compiles in the grey one
+ * (575-577), the others are a one-line edit there and a parameter here. */
+enum { RT_SKY_GREY = 0, RT_SKY_DAY = 1, RT_SKY_NIGHT = 2, RT_SKY_WHITE = 3, RT_SKY_BLACK = 4 };
 
 enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id per pixel       */
        RT_FLAG_PATH_HASH   = 2u,   /* record a hash of every nearest-hit id along the paths    */

@@ -215,6 +215,7 @@ struct Ctx {
     const RtoCamera* cam;
     const RtoPushConstants* pc;
     int math_mode;
+    int skybox = 0;
     int width, height;
     int px, py;        // gl_GlobalInvocationID.xy
     uint32_t seed;     // raytracer.comp:189
@@ -414,7 +415,29 @@ bool shadow_ray(Ctx& c, const Ray& r) {  // 511-515
     return hit_scene(c, r, i, h);
 }
 
-vec3 skybox_color(const Ray&) { return vec3(0.3f); }  // skybox_color_grey, 570-577
+// raytracer.comp:520-577: the five skybox functions; skybox_color() calls the grey one (575-577),
+// `kind` makes the one-line choice a parameter.  smoothstep and mix per the GLSL definitions.
+inline float gl_smoothstep(float e0, float e1, float x) {
+    const float t = gl_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+vec3 skybox_color(int kind, const Ray& r) {
+    if (kind == 0) return vec3(0.3f);  // skybox_color_grey, 570-572
+    if (kind == 3) return vec3(1.0f);  // skybox_color_white, 564-566
+    if (kind == 4) return vec3(0.0f);  // skybox_color_black, 567-569
+    const float size = 0.999f, bleed = 0.0003f;
+    const vec3 dir_unit = normalize(r.dir);
+    const float a = 0.5f * (dir_unit.y + 1.0f);
+    if (kind == 1) {  // skybox_color_day, 522-540: sun_dir is used as written, not normalised
+        const vec3 sky_gradient = gl_mix(vec3(0.231f, 0.756f, 0.945f), vec3(1.0f), a);
+        const float sun_dot = dot(vec3(-0.33f, 0.67f, -0.67f), dir_unit);
+        return gl_mix(sky_gradient, vec3(1.0f), gl_smoothstep(size - bleed, size + bleed, sun_dot));
+    }
+    // skybox_color_night, 543-561
+    const vec3 sky_gradient = gl_mix(vec3(0.0f), vec3(0.005f), a);
+    const float moon_dot = dot(normalize(vec3(0.33f, 0.67f, -0.67f)), dir_unit);
+    return gl_mix(sky_gradient, vec3(0.9f, 0.9f, 0.8f), gl_smoothstep(size - bleed, size + bleed, moon_dot));
+}
 
 // ----------------------------------------------------------------------------- lights, raytracer.comp:582-679
 vec3 sample_light(Ctx& c, vec3 point, vec3 normal, vec3& L, float& pdf) {
@@ -661,7 +684,7 @@ vec3 ray_color(Ctx& c, Ray r, int max_bounces) {
             r.orig = h.p;
             r.dir = bounce_dir;
         } else {
-            color = color + attenuation * skybox_color(r);
+            color = color + attenuation * skybox_color(c.skybox, r);
             return gl_clamp(color, 0.0f, 1.0f);
         }
     }
@@ -755,6 +778,7 @@ int rto_render(const RtoScene* scene, const RtoCamera* camera, const RtoPushCons
         Ctx c;
         c.sc = scene; c.cam = camera; c.pc = pc;
         c.math_mode = params->math_mode;
+        c.skybox = params->skybox;
         c.width = W; c.height = H;
         c.rays = 0; c.last_id = -1; c.path_hash = 0; c.primary_id = -1; c.primary_taken = false; c.seed = 0;
         for (size_t k = (size_t)tid; k < rows.size(); k += (size_t)nthreads) {

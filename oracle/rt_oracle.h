@@ -37,6 +37,7 @@ typedef struct {
     int32_t threads;               /* rows are dealt round-robin to this many threads */
     int32_t row_begin, row_end;    /* render rows [row_begin, row_end); row_end <= 0: height */
     int32_t strip_rows, strip_count, strip_index; /* strip_rows > 0: only rows with (y/strip_rows)%strip_count == strip_index */
+    int32_t skybox;                /* 0 grey (the shader's choice, raytracer.comp:575-577), 1 day, 2 night, 3 white, 4 black */
 } RtoParams;
 
 typedef struct {

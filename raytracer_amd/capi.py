@@ -37,6 +37,7 @@ RT_FLAG_POOLED = 32
 RT_FLAG_SINGLE_KERNEL = 64
 RT_FLAG_FIXED_TILE_ORDER = 128
 RT_MODEL_FULL_GLTF, RT_MODEL_REBASE_INDICES = 1, 2
+RT_SKY_GREY, RT_SKY_DAY, RT_SKY_NIGHT, RT_SKY_WHITE, RT_SKY_BLACK = 0, 1, 2, 3, 4
 RT_PIPELINE_SINGLE, RT_PIPELINE_STAGED, RT_PIPELINE_POOLED = 0, 1, 2
 
 RT_SCENE_EMPTY = 0
@@ -92,7 +93,7 @@ class RtPushConstants(C.Structure):
 
 class RtParams(C.Structure):
     _fields_ = [("spp", C.c_int32), ("max_bounces", C.c_int32), ("accel", C.c_int32), ("strip_rows", C.c_int32),
-                ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("flags", C.c_uint32)]
+                ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("flags", C.c_uint32), ("skybox", C.c_int32)]
 
 
 class RtStats(C.Structure):

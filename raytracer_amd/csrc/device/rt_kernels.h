@@ -41,6 +41,7 @@ struct FrameArgs {
     int32_t exit_quota_pct;  // the search loop returns once this share of the wave's busy lanes has finished
     int32_t accel;           // RT_ACCEL_*: which record array the search results index
     int32_t stack_depth;     // entries per traversal stack (staged pipeline: sized to the scene's BVH)
+    int32_t skybox;          // RT_SKY_*
     // outputs
     float4* accum;
     int32_t* counts;

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             need_shade = true;
         } else if (ready && state == ST_TRACE_PATH) {
             if (hit_idx < 0) {
-                col = col + att * v3(0.3f);  // skybox_color_grey, raytracer.comp:570-577, 924
+                col = col + att * skybox_color(fa.skybox, rd);  // raytracer.comp:575-577, 924
                 end_sample = true;
             } else {
                 make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);

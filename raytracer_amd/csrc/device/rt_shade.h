@@ -5,6 +5,31 @@
 
 namespace rtd {
 
+// What a ray that leaves the scene sees (raytracer.comp:520-577): `kind` selects among the shader's
+// skybox functions (0 grey, the one the reference compiles in; 1 day; 2 night; 3 white; 4 black).
+// smoothstep(e0, e1, x) = t*t*(3 - 2t), t = clamp((x - e0) / (e1 - e0), 0, 1); mix as g_mix.
+RT_DEV float g_smoothstep(float e0, float e1, float x) {
+    const float t = g_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+RT_DEV V3 skybox_color(int kind, V3 dir) {
+    if (kind == 0) return v3(0.3f);
+    if (kind == 3) return v3(1.0f);
+    if (kind == 4) return v3(0.0f);
+    const float size = 0.999f, bleed = 0.0003f;
+    const V3 d = normalize(dir);
+    const float a = 0.5f * (d.y + 1.0f);
+    if (kind == 1) {  // skybox_color_day, raytracer.comp:522-540 (its sun direction is used unnormalised)
+        const V3 grad = g_mix(v3(0.231f, 0.756f, 0.945f), v3(1.0f), a);
+        const float mask = g_smoothstep(size - bleed, size + bleed, dot(v3(-0.33f, 0.67f, -0.67f), d));
+        return g_mix(grad, v3(1.0f), mask);
+    }
+    // skybox_color_night, raytracer.comp:543-561
+    const V3 grad = g_mix(v3(0.0f), v3(0.005f), a);
+    const float mask = g_smoothstep(size - bleed, size + bleed, dot(normalize(v3(0.33f, 0.67f, -0.67f)), d));
+    return g_mix(grad, v3(0.9f, 0.9f, 0.8f), mask);
+}
+
 struct Material {  // raytracer.comp:54-82
     V3 albedo;        float albedo_a;
     V3 subsurface;    float subsurface_a;

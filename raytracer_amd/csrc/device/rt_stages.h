@@ -120,7 +120,7 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
         sl.get_hit(hit_t, hit_idx);
         int prim_id = -1;
         if (hit_idx < 0) {
-            sl.put_col(sl.get_col() + att * v3(0.3f));  // skybox_color_grey, raytracer.comp:570-577, 924
+            sl.put_col(sl.get_col() + att * skybox_color(fa.skybox, rd));  // raytracer.comp:575-577, 924
             to_end = true;
         } else {
             make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);

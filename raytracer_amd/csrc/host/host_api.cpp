@@ -23,6 +23,7 @@ void rt_default_params(RtParams* out) {
     out->strip_count = 1;
     out->strip_index = 0;
     out->flags = 0;
+    out->skybox = RT_SKY_GREY;  // raytracer.comp:575-577
 }
 
 int rt_scene_create(int preset, const char* assets_dir, RtScene** out) {

@@ -378,6 +378,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     if (p.spp <= 0 || p.max_bounces < 0 || p.spp > 65536 || p.max_bounces > 65536)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "spp / max_bounces out of range");
     if (p.accel != RT_ACCEL_FLAT && p.accel != RT_ACCEL_BVH) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown accel");
+    if (p.skybox < RT_SKY_GREY || p.skybox > RT_SKY_BLACK) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown skybox");
     if (p.strip_rows > 0 && (p.strip_count < 1 || p.strip_index < 0 || p.strip_index >= p.strip_count))
         return fail(c, RT_ERR_INVALID_ARGUMENT, "bad strip partition");
     // The acceleration structure was built for the uploaded element counts; the loop bounds
@@ -435,6 +436,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (v >= 1 && v <= 100) fa.exit_quota_pct = v;
     }
     fa.accel = p.accel;
+    fa.skybox = p.skybox;
     fa.stack_depth = c->bvh_depth + 2 < 4 ? 4 : (c->bvh_depth + 2 > rtd::kStackDepth ? rtd::kStackDepth : c->bvh_depth + 2);
     fa.accum = (float4*)c->d_accum;
     fa.counts = (int32_t*)c->d_counts;

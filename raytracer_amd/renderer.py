@@ -193,9 +193,9 @@ class Controller:
 
 
 def make_params(spp: int = 5, max_bounces: int = 20, accel: int = capi.RT_ACCEL_BVH, strip_rows: int = 0,
-                strip_count: int = 1, strip_index: int = 0, flags: int = 0) -> capi.RtParams:
+                strip_count: int = 1, strip_index: int = 0, flags: int = 0, skybox: int = capi.RT_SKY_GREY) -> capi.RtParams:
     return capi.RtParams(int(spp), int(max_bounces), int(accel), int(strip_rows), int(strip_count), int(strip_index),
-                         int(flags))
+                         int(flags), int(skybox))
 
 
 class Context:

@@ -12,7 +12,7 @@ DEBUG_FLAGS = capi.RT_FLAG_PRIMARY_IDS | capi.RT_FLAG_PATH_HASH
 
 
 def oracle_frames(scene: Scene, width, height, spp, max_bounces, frames=1, math_mode=0, camera=None, time=0.0,
-                  threads=8, strip=(0, 1, 0)):
+                  threads=8, strip=(0, 1, 0), skybox=0):
     cam = camera or default_camera(width, height)
     osc = ob.OracleScene(scene.arrays())
     acc = cnt = None
@@ -21,7 +21,7 @@ def oracle_frames(scene: Scene, width, height, spp, max_bounces, frames=1, math_
     for f in range(frames):
         pc = scene.push_constants(time, f, f == 0)
         out = ob.render(osc, cam, pc, width, height, spp, max_bounces, math_mode=math_mode, threads=threads, accum=acc,
-                        counts=cnt, strip=strip)
+                        counts=cnt, strip=strip, skybox=skybox)
         acc, cnt = out["accum"], out["counts"]
         total_rays += out["rays"]
     out["total_rays"] = total_rays
@@ -41,7 +41,7 @@ def oracle_render(scene: Scene, width, height, spp, max_bounces, inputs, math_mo
 
 
 def gpu_frames(ctx: Context, scene: Scene, width, height, spp, max_bounces, frames=1, accel=capi.RT_ACCEL_BVH,
-               camera=None, time=0.0, flags=DEBUG_FLAGS, strip=(0, 1, 0), upload=True, resize=True):
+               camera=None, time=0.0, flags=DEBUG_FLAGS, strip=(0, 1, 0), upload=True, resize=True, skybox=0):
     cam = camera or default_camera(width, height)
     if upload:
         ctx.upload_scene(scene)
@@ -50,7 +50,7 @@ def gpu_frames(ctx: Context, scene: Scene, width, height, spp, max_bounces, fram
     total_rays = 0
     for f in range(frames):
         pc = scene.push_constants(time, f, f == 0)
-        p = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags)
+        p = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags, skybox)
         ctx.render_frame(cam, pc, p)
         total_rays += ctx.stats().rays
     acc, cnt = ctx.read_accum()

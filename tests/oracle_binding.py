@@ -19,7 +19,7 @@ class RtoScene(C.Structure):
 
 class RtoParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "spp", "max_bounces", "math_mode", "threads", "row_begin",
-                                         "row_end", "strip_rows", "strip_count", "strip_index")]
+                                         "row_end", "strip_rows", "strip_count", "strip_index", "skybox")]
 
 
 class RtoOutputs(C.Structure):
@@ -68,7 +68,7 @@ class OracleScene:
 
 
 def render(scene: OracleScene, camera, pc, width, height, spp, max_bounces, math_mode=0, threads=8, accum=None,
-           counts=None, strip=(0, 1, 0), rows=(0, 0), want_debug=True):
+           counts=None, strip=(0, 1, 0), rows=(0, 0), want_debug=True, skybox=0):
     """One oracle frame.  `camera` / `pc` are ctypes structs with the 336 B / 44 B layouts.
     Returns dict(accum, counts, bgra, primary_ids, path_hash, rays)."""
     lib = load()
@@ -81,7 +81,7 @@ def render(scene: OracleScene, camera, pc, width, height, spp, max_bounces, math
     ids = np.full((height, width), -1, np.int32) if want_debug else None
     ph = np.zeros((height, width), np.uint32) if want_debug else None
     rays = C.c_uint64(0)
-    p = RtoParams(width, height, spp, max_bounces, math_mode, threads, rows[0], rows[1], strip[0], strip[1], strip[2])
+    p = RtoParams(width, height, spp, max_bounces, math_mode, threads, rows[0], rows[1], strip[0], strip[1], strip[2], skybox)
     o = RtoOutputs(accum.ctypes.data, counts.ctypes.data, bgra.ctypes.data, ids.ctypes.data if want_debug else None,
                    ph.ctypes.data if want_debug else None, C.addressof(rays))
     rc = lib.rto_render(C.byref(scene.c), C.addressof(camera), C.addressof(pc), C.byref(p), C.byref(o))

@@ -156,6 +156,25 @@ def test_light_types_transparency_and_transmission(ctx, kind, accel):
     assert np.isfinite(g["accum"]).all()
 
 
+@pytest.mark.parametrize("skybox", [capi.RT_SKY_DAY, capi.RT_SKY_NIGHT, capi.RT_SKY_WHITE, capi.RT_SKY_BLACK])
+def test_skybox_variants(ctx, star, skybox):
+    """The shader's other skybox functions (raytracer.comp:520-569) behind RtParams.skybox: bit-identical
+    to the oracle with the flat search, and the same bits from the pooled and the staged pipeline."""
+    from helpers import DEBUG_FLAGS
+    from raytracer_amd.renderer import look_camera
+    W, H = 80, 45
+    cam = look_camera((2.75, 2.75, -9.0), (0.15, 0.25, 1.0), (0.0, 1.0, 0.0), 70.0, W, H)  # box and plenty of sky
+    o = oracle_frames(star, W, H, spp=2, max_bounces=5, camera=cam, skybox=skybox)
+    g = gpu_frames(ctx, star, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_FLAT, camera=cam, skybox=skybox)
+    assert_identical(g, o)
+    assert (o["primary_ids"] < 0).mean() > 0.2
+    b = gpu_frames(ctx, star, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, camera=cam, skybox=skybox)
+    for fl in (capi.RT_FLAG_POOLED, capi.RT_FLAG_WAVEFRONT):
+        p = gpu_frames(ctx, star, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, camera=cam, skybox=skybox,
+                       flags=DEBUG_FLAGS | fl)
+        assert_identical(p, b)
+
+
 @pytest.mark.parametrize("accel", [capi.RT_ACCEL_FLAT, capi.RT_ACCEL_BVH])
 def test_scene_with_two_rebased_models(ctx, accel):
     """Two models in one scene (general GLB reader, indices rebased onto each model's vertices - the
@@ -217,6 +236,15 @@ def test_bvh_equals_flat_at_a_larger_size(ctx, teapot):
     b = gpu_frames(ctx, teapot, W, H, spp=2, max_bounces=4, accel=capi.RT_ACCEL_BVH)
     bad = assert_identical_but_edge_ties(b, f)
     print(f"edge-tie pixels at {W}x{H}: {bad}")
+
+
+def test_unknown_skybox_is_refused(ctx, star):
+    ctx.upload_scene(star)
+    ctx.resize(8, 8)
+    from raytracer_amd.renderer import RtError, default_camera
+    with pytest.raises(RtError) as e:
+        ctx.render_frame(default_camera(8, 8), star.push_constants(0.0, 0, True), make_params(1, 1, skybox=7))
+    assert e.value.code == capi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_error_codes(ctx, star):

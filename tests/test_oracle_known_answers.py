@@ -188,3 +188,50 @@ def test_tan_of_acos_and_pow_accuracy():
     assert lib.rto_math(4, 0, 0.0, 5.0) == 0.0 and lib.rto_math(4, 0, 1.0, 5.0) == 1.0
     assert math.isnan(lib.rto_math(4, 0, -0.5, 5.0))  # GLSL: pow undefined for x < 0 -> NaN via log2
     assert math.isnan(lib.rto_math(3, 0, 1.0000001, 0.0))
+
+
+# ------------------------------------------------------------------ skybox variants (raytracer.comp:520-577)
+def _sky_image(skybox, front=(0.0, 0.0, 1.0), W=32, H=18):
+    from helpers import oracle_frames
+    from raytracer_amd import capi
+    from raytracer_amd.renderer import Scene, look_camera
+    s = Scene(capi.RT_SCENE_EMPTY)
+    cam = look_camera((0.0, 0.0, 0.0), front, (0.0, 1.0, 0.0), 50.0, W, H)
+    return oracle_frames(s, W, H, spp=1, max_bounces=1, camera=cam, skybox=skybox)["accum"]
+
+
+def test_constant_skyboxes():
+    """Empty scene, one sample: every pixel is gamma(sky) (raytracer.comp:978-988)."""
+    import numpy as np
+    from raytracer_amd import capi
+    assert (_sky_image(capi.RT_SKY_WHITE)[..., :3] == 1.0).all()
+    assert (_sky_image(capi.RT_SKY_BLACK)[..., :3] == 0.0).all()
+    grey = _sky_image(capi.RT_SKY_GREY)[..., :3]
+    assert np.allclose(grey, 0.3 ** (1 / 2.2), atol=2e-6) and (grey == grey[0, 0, 0]).all()
+
+
+def test_day_sky_gradient_and_sun_disc():
+    """skybox_color_day (522-540): mix(horizon, zenith, 0.5*(dir.y+1)) - whiter towards the zenith, the
+    blue horizon colour's ordering of channels below it - and a white disc around the sun direction."""
+    import numpy as np
+    from raytracer_amd import capi
+    img = _sky_image(capi.RT_SKY_DAY)[..., :3]
+    col = img[:, 16]                          # one image column, top row first
+    assert (np.diff(col[:, 0]) < 0).all()     # red falls from the top of the image to the bottom
+    assert (col[:, 0] < col[:, 1]).all() and (col[:, 1] < col[:, 2]).all()  # 0.231 < 0.756 < 0.945 mixed with white
+    a = 0.5 * (0.0 + 1.0)                      # the centre rows look along the horizon: dir.y ~ 0
+    mid = (img[8, 16] + img[9, 16]) / 2
+    expect = (np.array([0.231, 0.756, 0.945]) * (1 - a) + a) ** (1 / 2.2)
+    assert np.allclose(mid, expect, atol=0.01)
+    sun = _sky_image(capi.RT_SKY_DAY, front=(-0.33, 0.67, -0.67), W=33, H=33)[..., :3]
+    assert (sun[16, 16] == 1.0).all() and sun[0, 0, 0] < 1.0
+
+
+def test_night_sky_is_dark_with_a_moon():
+    """skybox_color_night (543-561): zenith 0.005, horizon 0, moon colour (0.9, 0.9, 0.8) inside the disc."""
+    import numpy as np
+    from raytracer_amd import capi
+    img = _sky_image(capi.RT_SKY_NIGHT)[..., :3]
+    assert img.max() <= 0.005 ** (1 / 2.2) + 1e-6 and (np.diff(img[:, 5, 0]) < 0).all()
+    moon = _sky_image(capi.RT_SKY_NIGHT, front=(0.33, 0.67, -0.67), W=33, H=33)[..., :3]
+    assert np.allclose(moon[16, 16], np.array([0.9, 0.9, 0.8]) ** (1 / 2.2), atol=2e-6)
