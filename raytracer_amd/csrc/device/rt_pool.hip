@@ -110,6 +110,7 @@ struct PoolSlot {
     RT_DEV void get_hit(float& t, int& idx) const { t = L.hit_t[i]; idx = L.hit_idx[i]; }
     RT_DEV V3 get_col() const { return v3(L.col[0][i], L.col[1][i], L.col[2][i]); }
     RT_DEV void put_col(V3 v) const { L.col[0][i] = v.x; L.col[1][i] = v.y; L.col[2][i] = v.z; }
+    RT_DEV KernargFloats camera(const FrameArgs&) const { return kernarg_camera(); }  // pool_kernel(DeviceScene, FrameArgs, ...)
     RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t) const {}

@@ -42,6 +42,7 @@ struct GlobalSlot {
     RT_DEV void get_hit(float& t, int& idx) const { const uint2 r = pp.hit[s]; t = __uint_as_float(r.x); idx = (int)r.y; }
     RT_DEV V3 get_col() const { return xyz(pp.col[s]); }
     RT_DEV void put_col(V3 v) const { pp.col[s] = f4(v, 0.0f); }
+    RT_DEV const float* camera(const FrameArgs& fa) const { return fa.view_inv; }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = pp.pix[s]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { pp.pix[s] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t st) const { pp.stage[s] = st; }
@@ -192,7 +193,7 @@ template <typename Slot>
 RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t phash) {
     const int px = (int)(pixel % (uint32_t)fa.width), py = (int)(pixel / (uint32_t)fa.width);
     V3 ro, rd;
-    generate_ray(fa, px, py, seed, ro, rd);
+    generate_ray(fa, sl.camera(fa), px, py, seed, ro, rd);
     sl.put_ctl(seed, pixel, sample, 0);
     sl.put_ro(ro);
     sl.put_rd(rd);

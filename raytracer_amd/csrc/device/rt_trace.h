@@ -2,6 +2,7 @@
 // (rt_kernels.hip) and the staged pipeline (rt_wavefront.hip): one primitive test with the
 // reference's tie rules, the resumable BVH step, the hit record and the rgba8 store.
 #pragma once
+#include <cstddef>
 #include "rt_kernels.h"
 #include "rt_shade.h"
 
@@ -230,8 +231,23 @@ RT_DEV uint32_t resolve_pixel(float4 a, int c) {
     return pack_unorm8(a.z / d) | (pack_unorm8(a.y / d) << 8) | (pack_unorm8(a.x / d) << 16) | (pack_unorm8(a.w / d) << 24);
 }
 
-// get_ray, raytracer.comp:933-952: jittered primary ray through pixel (px, py).
-RT_DEV void generate_ray(const FrameArgs& fa, int px, int py, uint32_t& seed, V3& ro, V3& rd) {
+// The camera block (view_inv[16], cam_pos[3], tan_half_fov: the first 20 floats of FrameArgs) read from
+// the kernel-argument segment where it is used, through a pointer the compiler cannot trace back: as a
+// by-value argument it would sit in 20 scalar registers for the whole kernel, which the persistent
+// kernels are short of (they spill scalars into vector lanes).  Only for kernels whose arguments begin
+// with (DeviceScene, FrameArgs).
+typedef const __attribute__((address_space(4))) float* KernargFloats;
+static_assert(offsetof(FrameArgs, view_inv) == 0 && offsetof(FrameArgs, cam_pos) == 64 && offsetof(FrameArgs, tan_half_fov) == 76,
+              "the camera block must open FrameArgs");
+RT_DEV KernargFloats kernarg_camera() {
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (KernargFloats)(p + ((sizeof(DeviceScene) + alignof(FrameArgs) - 1) & ~(alignof(FrameArgs) - 1)));
+}
+
+// get_ray, raytracer.comp:933-952: jittered primary ray through pixel (px, py); `cam` = the camera block.
+template <typename CamPtr>
+RT_DEV void generate_ray(const FrameArgs& fa, CamPtr cam, int px, int py, uint32_t& seed, V3& ro, V3& rd) {
     const float aspect = (float)fa.width / (float)fa.height;  // raytracer.comp:187
     float sx = rng_random(seed) - 0.5f;
     float sy = rng_random(seed) - 0.5f;
@@ -239,13 +255,14 @@ RT_DEV void generate_ray(const FrameArgs& fa, int px, int py, uint32_t& seed, V3
     float fy = (float)py + sy;
     float ndcX = 2.0f * fx / (float)fa.width - 1.0f;
     float ndcY = 1.0f - 2.0f * fy / (float)fa.height;
-    V3 dc = normalize(v3(ndcX * aspect * fa.tan_half_fov, ndcY * fa.tan_half_fov, -1.0f));
-    const float* m = fa.view_inv;
+    const float tan_half_fov = cam[19];
+    V3 dc = normalize(v3(ndcX * aspect * tan_half_fov, ndcY * tan_half_fov, -1.0f));
+    const CamPtr m = cam;  // view_inv[16], cam_pos[3], tan_half_fov: the first 20 floats of FrameArgs
     V3 dw = v3(m[0] * dc.x + m[4] * dc.y + m[8] * dc.z + m[12] * 0.0f,
                m[1] * dc.x + m[5] * dc.y + m[9] * dc.z + m[13] * 0.0f,
                m[2] * dc.x + m[6] * dc.y + m[10] * dc.z + m[14] * 0.0f);
     rd = normalize(dw);
-    ro = v3(fa.cam_pos[0], fa.cam_pos[1], fa.cam_pos[2]);
+    ro = v3(cam[16], cam[17], cam[18]);
 }
 
 // Pixel slot -> image coordinates: slots walk 8x8 tiles row-major over the rows this
