@@ -111,6 +111,7 @@ struct PoolSlot {
     RT_DEV V3 get_col() const { return v3(L.col[0][i], L.col[1][i], L.col[2][i]); }
     RT_DEV void put_col(V3 v) const { L.col[0][i] = v.x; L.col[1][i] = v.y; L.col[2][i] = v.z; }
     RT_DEV KernargFloats camera(const FrameArgs&) const { return kernarg_camera(); }  // pool_kernel(DeviceScene, FrameArgs, ...)
+    RT_DEV FrameArgs late_frame(const FrameArgs&) const { return kernarg_frame(); }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t) const {}
@@ -230,7 +231,9 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
 // of the frame come from the workgroup's reserve, refilled kChunk at a time from the frame's
 // counter (one global atomic per kChunk pixels; the reserve is handed out under a small LDS
 // lock, taken a few hundred times per frame).  A slot that finds the frame exhausted dies.
-RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa, float4* cold_base, bool need, uint32_t local) {
+RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, bool need, uint32_t local) {
+    if (__ballot(need) == 0ull) return false;
+    const FrameArgs fa = kernarg_frame();  // once per pixel: not worth scalar registers for the whole kernel
     bool started = false, dead = false;
     for (;;) {
         const unsigned long long m = __ballot(need);

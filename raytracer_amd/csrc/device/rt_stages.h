@@ -43,6 +43,7 @@ struct GlobalSlot {
     RT_DEV V3 get_col() const { return xyz(pp.col[s]); }
     RT_DEV void put_col(V3 v) const { pp.col[s] = f4(v, 0.0f); }
     RT_DEV const float* camera(const FrameArgs& fa) const { return fa.view_inv; }
+    RT_DEV const FrameArgs& late_frame(const FrameArgs& fa) const { return fa; }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = pp.pix[s]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { pp.pix[s] = f4(v, cost); }
     RT_DEV void put_stage(uint32_t st) const { pp.stage[s] = st; }
@@ -219,21 +220,22 @@ RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
         start_sample(fa, sl, seed, pixel, sample, phash);
         alive = true;
     } else {
-        V3 cc = g_pow(pix / (float)fa.spp, 1.0f / 2.2f);
+        const auto& ff = sl.late_frame(fa);  // the frame's arguments, possibly loaded only here
+        V3 cc = g_pow(pix / (float)ff.spp, 1.0f / 2.2f);
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int n = 0;
-        if (!fa.reset) {
-            a = fa.accum[pixel];
-            n = fa.counts[pixel];
+        if (!ff.reset) {
+            a = ff.accum[pixel];
+            n = ff.counts[pixel];
         }
         a.x += cc.x; a.y += cc.y; a.z += cc.z; a.w += 1.0f;
         n += 1;
-        fa.accum[pixel] = a;
-        fa.counts[pixel] = n;
-        fa.bgra[pixel] = resolve_pixel(a, n);
-        if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[pixel] = phash;
-        const int py = (int)(pixel / (uint32_t)fa.width);
-        report_pixel_cost(fa, (int)pixel - py * fa.width, py, (uint32_t)cost);
+        ff.accum[pixel] = a;
+        ff.counts[pixel] = n;
+        ff.bgra[pixel] = resolve_pixel(a, n);
+        if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
+        const int py = (int)(pixel / (uint32_t)ff.width);
+        report_pixel_cost(ff, (int)pixel - py * ff.width, py, (uint32_t)cost);
         sl.put_stage(WF_IDLE);
         alive = false;
     }

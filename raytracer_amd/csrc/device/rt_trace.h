@@ -244,6 +244,17 @@ RT_DEV KernargFloats kernarg_camera() {
     asm volatile("" : "+s"(p));
     return (KernargFloats)(p + ((sizeof(DeviceScene) + alignof(FrameArgs) - 1) & ~(alignof(FrameArgs) - 1)));
 }
+// The same for the whole of FrameArgs: a copy whose fields are loaded where this is called (only the
+// fields the caller goes on to use), for the parts of a kernel that run once per pixel.
+RT_DEV FrameArgs kernarg_frame() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const __attribute__((address_space(4))) FrameArgs*)(p + ((sizeof(DeviceScene) + alignof(FrameArgs) - 1) & ~(alignof(FrameArgs) - 1)));
+#else
+    return FrameArgs{};  // the host pass only parses device functions
+#endif
+}
 
 // get_ray, raytracer.comp:933-952: jittered primary ray through pixel (px, py); `cam` = the camera block.
 template <typename CamPtr>
