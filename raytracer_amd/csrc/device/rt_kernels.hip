@@ -116,12 +116,13 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             if (res_left != 0u) {
                 const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (state == ST_IDLE && rank < res_left) {
+                    const FrameArgs ff = kernarg_frame();  // once per pixel: loaded here, not held in scalar registers
                     int x, y;
-                    if (slot_to_pixel(fa, res_next + rank, x, y)) {
+                    if (slot_to_pixel(ff, res_next + rank, x, y)) {
                         px = x;
                         py = y;
                         // raytracer.comp:959-961
-                        seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
+                        seed = rng_hash(ff.time_u * 1920u) ^ rng_hash(ff.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
                         pix = v3(0.0f);
                         sample = 0;
                         phash = 0;
@@ -144,13 +145,14 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             float fy = (float)py + sy;
             float ndcX = 2.0f * fx / (float)fa.width - 1.0f;
             float ndcY = 1.0f - 2.0f * fy / (float)fa.height;
-            V3 dc = normalize(v3(ndcX * aspect * fa.tan_half_fov, ndcY * fa.tan_half_fov, -1.0f));
-            const float* m = fa.view_inv;
+            const KernargFloats m = kernarg_camera();  // view_inv[16], cam_pos[3], tan_half_fov
+            const float tan_half_fov = m[19];
+            V3 dc = normalize(v3(ndcX * aspect * tan_half_fov, ndcY * tan_half_fov, -1.0f));
             V3 dw = v3(m[0] * dc.x + m[4] * dc.y + m[8] * dc.z + m[12] * 0.0f,
                        m[1] * dc.x + m[5] * dc.y + m[9] * dc.z + m[13] * 0.0f,
                        m[2] * dc.x + m[6] * dc.y + m[10] * dc.z + m[14] * 0.0f);
             rd = normalize(dw);
-            ro = v3(fa.cam_pos[0], fa.cam_pos[1], fa.cam_pos[2]);
+            ro = v3(m[16], m[17], m[18]);
             att = v3(1.0f);
             col = v3(0.0f);
             bounce = 0;
@@ -385,21 +387,22 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                 state = -1;
             } else {
                 // raytracer.comp:978-995
-                V3 c = g_pow(pix / (float)fa.spp, 1.0f / 2.2f);
-                const int idx = py * fa.width + px;
+                const FrameArgs ff = kernarg_frame();
+                V3 c = g_pow(pix / (float)ff.spp, 1.0f / 2.2f);
+                const int idx = py * ff.width + px;
                 float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 int n = 0;
-                if (!fa.reset) {
-                    a = fa.accum[idx];
-                    n = fa.counts[idx];
+                if (!ff.reset) {
+                    a = ff.accum[idx];
+                    n = ff.counts[idx];
                 }
                 a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0f;
                 n += 1;
-                fa.accum[idx] = a;
-                fa.counts[idx] = n;
-                fa.bgra[idx] = resolve_pixel(a, n);
-                if ((fa.flags & 2u) && fa.path_hash != nullptr) fa.path_hash[idx] = phash;
-                report_pixel_cost(fa, px, py, cost);
+                ff.accum[idx] = a;
+                ff.counts[idx] = n;
+                ff.bgra[idx] = resolve_pixel(a, n);
+                if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[idx] = phash;
+                report_pixel_cost(ff, px, py, cost);
                 state = ST_IDLE;
             }
         }
