@@ -353,10 +353,11 @@ def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, st
     assert owned.any() and (a["counts"][owned] == 3).all()
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
 def test_full_size_frames_agree_across_pipelines(ctx, workload):
-    """BASELINE.json's full sizes (1920x1080; C2: 4 spp x 20 bounces on the star scene, C3: 16 spp
-    x 4 bounces on the teapot scene), too large for the oracle: the single kernel and the pooled
+    """BASELINE.json's full sizes (C2: 1920x1080, 4 spp x 20 bounces on the star scene; C3: 1920x1080,
+    16 spp x 4 bounces on the teapot scene; C4: the same scene at 3840x2160, 4 spp x 20 bounces per frame;
+    C5: 1.07 M triangles, 1920x1080, 8 spp x 20 bounces), too large for the oracle: the single kernel and the pooled
     schedule are independent orders of execution of the same 2 million pixels and must give the
     same accumulated floats, counts, BGRA8 bytes, per-pixel path hashes and ray count; two
     accumulated frames also check that frame N+1 sees frame N's accumulation."""
