@@ -80,6 +80,8 @@ struct PoolLds {
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
 static_assert(kQueues == 5 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
+static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing, "a queue entry is a 12-bit slot index plus a kind, and a ring holds every slot");
+static_assert(kThreads % 64 == 0 && kThreads <= 1024, "whole waves, one workgroup");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
