@@ -157,7 +157,7 @@ def main() -> None:
     # The library times its two kernels against each other on a configuration's first frames and
     # orders the tiles by the previous frame's costs: settle that before the W warm-up steps, so
     # that the timed frames are steady-state frames whatever W is.
-    SETTLE = 4
+    SETTLE = 6
     for f in range(SETTLE):
         step(f)
     for f in range(args.warmup):

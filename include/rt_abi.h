@@ -150,8 +150,8 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
                                       dearest-first as measured on the previous frame of the same
                                       size; same results, only the schedule differs              */ };
 /* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: with
- * the BVH and at least 16384 pixels it times the pooled kernel (frame 2 of a configuration) against
- * the single kernel (frame 3) and keeps the faster from frame 4 on; otherwise the single kernel.
+ * the BVH and at least 16384 pixels it times the pooled kernel (third frame of a configuration)
+ * against the single kernel (fifth frame) and keeps the faster from the sixth frame on; otherwise the single kernel.
  * All pipelines give the same bits. */
 enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_STAGED = 1, RT_PIPELINE_POOLED = 2 };
 

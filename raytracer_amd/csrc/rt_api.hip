@@ -53,7 +53,7 @@ struct RtContext {
     // choice between the pooled and the single kernel by measurement (see rt_render_frame)
     int32_t scene_generation = 0;
     int32_t tune_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int tune_stage = 0;       // 0: first pooled frame (no tile order yet), 1: pooled, timed, 2: single, timed, 3: decided
+    int tune_stage = 0;       // frames of this configuration so far (saturating): 0-2 pooled, 3-4 single, then the choice
     float tune_pooled_ms = 0.0f;
     int tune_choice = RT_PIPELINE_POOLED;
 
@@ -481,7 +481,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     // kernel time of the previous frame while its events are still intact: needed when that frame
     // was one of the timed trials of the pipeline choice below
     float prev_ms = -1.0f;
-    if (c->timed && (c->tune_stage == 2 || c->tune_stage == 3)) {
+    if (c->timed && (c->tune_stage == 3 || c->tune_stage == 5)) {
         float ms = 0.0f;
         if (hipEventSynchronize(c->ev_end) == hipSuccess && hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess)
             prev_ms = ms;
@@ -514,13 +514,15 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
                     memcpy(c->tune_key, key, sizeof key);
                     c->tune_stage = 0;
                 }
-                if (prev_ms >= 0.0f && c->tune_stage == 2) c->tune_pooled_ms = prev_ms;
-                if (prev_ms >= 0.0f && c->tune_stage == 3)
+                // frames 0-2 pooled (the third one timed, once the tile order and the clocks have settled),
+                // frames 3-4 single (the second one timed), from frame 5 on the faster of the two
+                if (prev_ms >= 0.0f && c->tune_stage == 3) c->tune_pooled_ms = prev_ms;
+                if (prev_ms >= 0.0f && c->tune_stage == 5)
                     c->tune_choice = (prev_ms < c->tune_pooled_ms) ? RT_PIPELINE_SINGLE : RT_PIPELINE_POOLED;
-                if (c->tune_stage <= 1) pipeline = RT_PIPELINE_POOLED;
-                else if (c->tune_stage == 2) pipeline = RT_PIPELINE_SINGLE;
+                if (c->tune_stage <= 2) pipeline = RT_PIPELINE_POOLED;
+                else if (c->tune_stage <= 4) pipeline = RT_PIPELINE_SINGLE;
                 else pipeline = c->tune_choice;
-                if (c->tune_stage < 4) c->tune_stage++;
+                if (c->tune_stage < 6) c->tune_stage++;
             }
         }
         c->last_pipeline = pipeline;

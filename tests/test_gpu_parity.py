@@ -370,21 +370,22 @@ def test_full_size_frames_agree_across_pipelines(ctx, workload):
     b = gpu_frames(ctx, s, W, H, spp, mb, frames=2, accel=capi.RT_ACCEL_BVH, camera=cam, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
     assert_identical(b, a)
     assert a["stats"].pipeline == capi.RT_PIPELINE_SINGLE and b["stats"].pipeline == capi.RT_PIPELINE_POOLED
-    # left to itself the library starts a configuration on the pooled schedule, times it against the
-    # single kernel on the third frame and keeps the faster (and without the hash the light queries
-    # are bounded): five such frames, whatever ran them, are the five frames of the single kernel
-    a5 = gpu_frames(ctx, s, W, H, spp, mb, frames=5, accel=capi.RT_ACCEL_BVH, camera=cam, flags=capi.RT_FLAG_SINGLE_KERNEL)
+    # left to itself the library runs a configuration's first three frames on the pooled schedule, the
+    # next two on the single kernel, and from then on the faster of the two timed ones (and without the
+    # hash the light queries are bounded): seven such frames, whatever ran them, are seven frames of the
+    # single kernel
+    a5 = gpu_frames(ctx, s, W, H, spp, mb, frames=7, accel=capi.RT_ACCEL_BVH, camera=cam, flags=capi.RT_FLAG_SINGLE_KERNEL)
     ctx.upload_scene(s)
     ctx.resize(W, H)
     used = []
-    for f in range(5):
+    for f in range(7):
         ctx.render_frame(cam, s.push_constants(0.0, f, f == 0), make_params(spp, mb, capi.RT_ACCEL_BVH))
         used.append(ctx.stats().pipeline)
-    assert used[:3] == [capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_SINGLE]
-    assert used[3] == used[4] and used[3] in (capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_SINGLE)
+    assert used[:5] == [capi.RT_PIPELINE_POOLED] * 3 + [capi.RT_PIPELINE_SINGLE] * 2
+    assert used[5] == used[6] and used[5] in (capi.RT_PIPELINE_POOLED, capi.RT_PIPELINE_SINGLE)
     acc, cnt = ctx.read_accum()
     assert bit_equal_pixels(acc, a5["accum"]).all() and np.array_equal(ctx.read_bgra8(), a5["bgra"])
-    assert (cnt == 5).all()
+    assert (cnt == 7).all()
     assert (a["counts"] == 2).all()
     assert np.isfinite(a["accum"]).all()
     # every pixel's BGRA8 byte is the rounded mean of its accumulated colour (raytracer.comp:992-995)
