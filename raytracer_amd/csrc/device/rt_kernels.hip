@@ -471,7 +471,22 @@ __global__ void __launch_bounds__(256) math_probe_kernel(int fn, const float* __
         case 9: r = g_sqrt(a); break;
         case 10: { uint32_t s = __float_as_uint(a); r = rng_random(s); } break;
         case 11: r = a * b + a; break;       // must stay two roundings (no contraction)
-        case 12: r = 1.0f / g_sqrt(a * a + b * b); break;
+        case 12: r = g_rcp_sqrt(a * a + b * b); break;
+        case 13: r = g_rcp(a); break;
+        case 14: r = g_rcp_sqrt(a); break;
+        // 100..102: sweeps over all 2^32 bit patterns, element i taking patterns i, i + n, ...: the number of
+        // patterns on which the short form and the compiler's IEEE expansion differ (two NaNs are equal)
+        // 103: the unguarded reciprocal form, which must differ outside its range (a check of the sweep itself)
+        case 100: case 101: case 102: case 103: {
+            uint32_t bad = 0;
+            for (uint64_t p = (uint64_t)i; p < (1ull << 32); p += (uint64_t)n) {
+                const float v = __uint_as_float((uint32_t)p);
+                const float s = fn == 100 ? g_rcp(v) : fn == 101 ? g_sqrt(v) : fn == 102 ? g_rcp_sqrt(v) : rcp_short(v);
+                const float e = (fn == 100 || fn == 103) ? ieee_div(1.0f, v) : fn == 101 ? ieee_sqrt(v) : ieee_div(1.0f, ieee_sqrt(v));
+                if (__float_as_uint(s) != __float_as_uint(e) && !(is_nan(s) && is_nan(e))) ++bad;
+            }
+            r = (float)bad;
+        } break;
         default: break;
     }
     out[i] = r;

@@ -29,7 +29,51 @@ RT_DEV float g_clamp(float x, float lo, float hi) { return g_min(g_max(x, lo), h
 RT_DEV float g_abs(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 RT_DEV float g_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 RT_DEV float g_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
-RT_DEV float g_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE sqrt under -fhip-fp32-correctly-rounded-divide-sqrt
+
+// ---- correctly rounded 1/x and sqrt(x) in short form -------------------------------------
+// The compiler's expansions of IEEE division and square root (11 and 14 instructions, about 47
+// and 55 issue cycles per wave) spend half of that on range scaling and special-case fix-up.
+// Inside the ranges below the hardware estimate plus one Newton round in fused arithmetic gives
+// the correctly rounded result already: compared with the expansions over ALL 2^32 bit patterns
+// on the device (rt_debug_math sweeps, tools/ubench/exact_math.hip), no input inside the ranges
+// differs.  Outside (zero, subnormal, huge, infinite, NaN) the expansions themselves run.
+RT_DEV float ieee_div(float a, float b) { return a / b; }
+RT_DEV float ieee_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE under -fhip-fp32-correctly-rounded-divide-sqrt
+// biased exponent 1..252: 2^-126 <= |x| < 2^126 (the reciprocal of anything larger is subnormal)
+RT_DEV bool rcp_short_ok(float x) { return ((f2u(x) & 0x7f800000u) - 0x00800000u) < 0x7e000000u; }
+// positive, biased exponent 26..254: 2^-101 <= x < 2^128
+RT_DEV bool sqrt_short_ok(float x) { return (f2u(x) - 0x0d000000u) < 0x72800000u; }
+RT_DEV float rcp_short(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+RT_DEV float sqrt_short(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r;
+    const float h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
+// The choice is made per wave (one scalar branch; a per-lane branch costs six scalar instructions of
+// exec-mask bookkeeping): the expansion is right for every input, so a wave with one lane out of
+// range runs it for all its lanes.
+RT_DEV bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+RT_DEV float g_rcp(float x) {  // 1.0f / x
+    if (__builtin_expect(wave_all(rcp_short_ok(x)), 1)) return rcp_short(x);
+    return ieee_div(1.0f, x);
+}
+RT_DEV float g_sqrt(float x) {
+    if (__builtin_expect(wave_all(sqrt_short_ok(x)), 1)) return sqrt_short(x);
+    return ieee_sqrt(x);
+}
+// 1.0f / sqrt(x), two roundings: the root of an in-range x lies in [2^-51, 2^64), inside the reciprocal's range
+RT_DEV float g_rcp_sqrt(float x) {
+    if (__builtin_expect(wave_all(sqrt_short_ok(x)), 1)) return rcp_short(sqrt_short(x));
+    return ieee_div(1.0f, ieee_sqrt(x));
+}
 
 // ---- trigonometry: Cody-Waite reduction by pi/4 octants + minimax polynomials ----------
 static constexpr float kFOPI = 1.27323954473516f;
@@ -118,7 +162,7 @@ RT_DEV float g_tan(float xx) {
     } else {
         r = z;
     }
-    if (j & 2) r = -1.0f / r;
+    if (j & 2) r = -g_rcp(r);
     return neg ? -r : r;
 }
 
@@ -234,7 +278,7 @@ RT_DEV V3 operator-(float s, V3 a) { return {s - a.x, s - a.y, s - a.z}; }
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV V3 cross(V3 a, V3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
 RT_DEV float length(V3 a) { return g_sqrt(dot(a, a)); }
-RT_DEV V3 normalize(V3 a) { return a * (1.0f / g_sqrt(dot(a, a))); }
+RT_DEV V3 normalize(V3 a) { return a * g_rcp_sqrt(dot(a, a)); }
 RT_DEV V3 g_max(V3 a, V3 b) { return {g_max(a.x, b.x), g_max(a.y, b.y), g_max(a.z, b.z)}; }
 RT_DEV V3 g_clamp(V3 a, float lo, float hi) { return {g_clamp(a.x, lo, hi), g_clamp(a.y, lo, hi), g_clamp(a.z, lo, hi)}; }
 RT_DEV V3 g_mix(V3 x, V3 y, float a) { return {g_mix(x.x, y.x, a), g_mix(x.y, y.y, a), g_mix(x.z, y.z, a)}; }

@@ -26,7 +26,10 @@ RT_DEV V3 skybox_color(int kind, V3 dir) {
     }
     // skybox_color_night, raytracer.comp:543-561
     const V3 grad = g_mix(v3(0.0f), v3(0.005f), a);
-    const float mask = g_smoothstep(size - bleed, size + bleed, dot(normalize(v3(0.33f, 0.67f, -0.67f)), d));
+    // normalize(vec3(0.33, 0.67, -0.67)) evaluated in binary32 under the arithmetic contract (dot, sqrt,
+    // reciprocal, three products), written out so that it is a literal and not run-time work
+    const V3 kMoonDir = v3(0x1.50cb2cp-2f, 0x1.55e586p-1f, -0x1.55e586p-1f);
+    const float mask = g_smoothstep(size - bleed, size + bleed, dot(kMoonDir, d));
     return g_mix(grad, v3(0.9f, 0.9f, 0.8f), mask);
 }
 
@@ -209,7 +212,7 @@ RT_DEV V3 eval_mat(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) 
 
     if (reflect_side) {
         float ior_scale = g_mix(0.0f, 2.0f, mat.specular_tint_a);
-        float ri = rec.front_face ? (1.0f / (mat.ior * ior_scale)) : mat.ior * ior_scale;
+        float ri = rec.front_face ? g_rcp(mat.ior * ior_scale) : mat.ior * ior_scale;
         float dielectric_F0 = (1.0f - ri) / (1.0f + ri);
         V3 dielectric_F0_vec = v3(dielectric_F0 * dielectric_F0);
         V3 F0 = g_mix(dielectric_F0_vec, mat.albedo, mat.metallic);
@@ -217,7 +220,7 @@ RT_DEV V3 eval_mat(const Material& mat, V3 L, V3 V, const Hit& rec, float& pdf) 
         V3 F = g_clamp(F0 + (1.0f - F0) * pw, 0.0f, 1.0f);  // reflectance(VdotH, F0), raytracer.comp:686-688
         float ks = g_max(g_max(F.x, F.y), F.z);
         float kd = (1.0f - ks) * (1.0f - mat.metallic);
-        float jacobian = 1.0f / g_max(0.00001f, 4.0f * NdotV * NdotL);
+        float jacobian = g_rcp(g_max(0.00001f, 4.0f * NdotV * NdotL));
         V3 f_specular = mat.specular_tint * D * G * F * jacobian;
         float pdf_specular = g_clamp(D * NdotH * jacobian, 0.0f, 1.0f);
         float pdf_diffuse = g_clamp(NdotL / kPi, 0.0f, 1.0f);

@@ -39,7 +39,7 @@ RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3
         V3 h = cross(rd, e2);
         float a = dot(e1, h);
         if (g_abs(a) < 1e-6f) return;
-        float f = 1.0f / a;
+        float f = g_rcp(a);
         V3 s = ro - v3(A.x, A.y, A.z);
         float u = f * dot(s, h);
         if (u < 0.0f || u > 1.0f) return;

@@ -74,3 +74,41 @@ def test_rng_float(ctx):
     g = ctx.debug_math(10, states.view(np.float32))
     o = np.array([lib.rto_random_from(int(s)) for s in states], dtype=np.float32)
     assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+
+
+def test_short_reciprocal_and_root_against_the_host(ctx):
+    """g_rcp / g_sqrt / g_rcp_sqrt (hardware estimate + one fused Newton round inside a range,
+    the compiler's IEEE expansion outside) on random bit patterns of every exponent and on the
+    special values: the host's correctly rounded 1/x, sqrt(x), 1/sqrt(x)."""
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 1 << 32, 300000, dtype=np.uint64).astype(np.uint32)
+    x = np.concatenate([bits.view(np.float32), samples(0, 1, 10, rng),
+                        np.array([2.0 ** -126, 2.0 ** -127, 2.0 ** 126, 2.0 ** 127, 2.0 ** -101, 2.0 ** -102, 3.0e38], dtype=np.float32)])
+    y = np.zeros_like(x)
+    with np.errstate(all="ignore"):
+        want = {13: np.float32(1.0) / x, 9: np.sqrt(x), 14: np.float32(1.0) / np.sqrt(x)}
+    for fn, w in want.items():
+        g = ctx.debug_math(fn, x, y)
+        same = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+        assert same.all(), f"fn {fn}: {np.count_nonzero(~same)} mismatches, x={x[~same][:5]} g={g[~same][:5]} want={w[~same][:5]}"
+
+
+@pytest.mark.parametrize("fn", [100, 101, 102])
+def test_short_forms_equal_the_ieee_expansions_on_every_bit_pattern(ctx, fn):
+    """All 2^32 inputs on the device: the short forms and the compiler's IEEE expansions agree
+    (element i of the probe counts the disagreements on patterns i, i + n, ...)."""
+    n = 1 << 20
+    z = np.zeros(n, dtype=np.float32)
+    bad = ctx.debug_math(fn, z, z)
+    assert float(bad.sum()) == 0.0, f"fn {fn}: {int(bad.sum())} bit patterns differ"
+
+
+def test_the_sweep_sees_differences(ctx):
+    """Control for the sweeps above: without its range guard the short reciprocal differs from 1/x on
+    every subnormal, on every |x| >= 2^126 (subnormal reciprocals) and on the infinities."""
+    n = 1 << 20
+    z = np.zeros(n, dtype=np.float32)
+    bad = ctx.debug_math(103, z, z).astype(np.float64).sum()
+    subnormals = 2 * ((1 << 23) - 1)      # both signs, zero excluded (1/0 = inf either way)
+    huge = 2 * 2 * (1 << 23)              # biased exponents 253 and 254
+    assert subnormals + huge <= bad <= subnormals + huge + 4, bad
