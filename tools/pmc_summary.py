@@ -17,3 +17,35 @@ for f in sorted(glob.glob(root + "/*/*/*counter_collection.csv")):
         acc[name].extend(v for _, v in rows[skip:])
 for k, v in sorted(acc.items()):
     print(f"{k:32s} launches={len(v):3d} avg={sum(v)/len(v):.6g}")
+
+# ---- derived figures (MI355X: 256 CUs x 4 SIMDs, 8 XCDs; SQ cycle counters tick once per 4 clocks) ----
+m = {k: sum(v) / len(v) for k, v in acc.items()}
+def have(*names):
+    return all(n in m for n in names)
+print("# derived")
+if have("GRBM_GUI_ACTIVE"):
+    clocks = m["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+    print(f"# kernel clocks per launch            {clocks:.4g}  (= {clocks / 2.4e6:.2f} ms at 2.4 GHz)")
+    simd_quads = 1024.0 * clocks / 4.0
+    if have("SQ_ACTIVE_INST_VALU"):
+        print(f"# VALU-active wave time / SIMD time   {m['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}  (instructions of different waves overlap in the pipeline: ~1 = saturated)")
+    if have("SQ_ACTIVE_INST_SCA"):
+        print(f"# scalar-active wave time / SIMD time {m['SQ_ACTIVE_INST_SCA'] / simd_quads:.3f}")
+    if have("SQ_WAVE_CYCLES"):
+        print(f"# waves resident per SIMD             {m['SQ_WAVE_CYCLES'] / simd_quads:.2f}")
+    if have("TA_BUSY_avr"):
+        print(f"# L1 / texture-address path busy      {m['TA_BUSY_avr'] / clocks:.3f}")
+    if have("TCC_REQ_sum"):
+        print(f"# L2 requests                         {m['TCC_REQ_sum'] * 128.0 / (clocks / 2.4e9) / 1e9:.0f} GB/s at 128 B each (upper bound: 16-B gathers fill little of a line)")
+    if have("FETCH_SIZE", "WRITE_SIZE"):
+        print(f"# HBM-side traffic                    {(m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024.0 / (clocks / 2.4e9) / 1e9:.0f} GB/s of 8000")
+if have("SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"):
+    print(f"# VALU lane utilisation               {m['SQ_THREAD_CYCLES_VALU'] / (64.0 * m['SQ_ACTIVE_INST_VALU']):.3f}")
+if have("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"):
+    print(f"# wave cycles waiting on memory/LDS   {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}")
+if have("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"):
+    print(f"# wave cycles waiting to issue        {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.3f}")
+if have("TCC_HIT_sum", "TCC_REQ_sum"):
+    print(f"# L2 hit rate                         {m['TCC_HIT_sum'] / m['TCC_REQ_sum']:.3f}")
+if have("TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"):
+    print(f"# L1 hit rate                         {1.0 - m['TCP_TCC_READ_REQ_sum'] / m['TCP_TOTAL_CACHE_ACCESSES_sum']:.3f}")
