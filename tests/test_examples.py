@@ -20,9 +20,14 @@ def run(args, **kw):
     return subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=120, **kw)
 
 
-def test_examples_build_against_the_header_and_library():
+def build_examples():
     r = subprocess.run(["make", "-C", EX], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def test_examples_build_against_the_header_and_library():
+    r = build_examples()
     assert "warning" not in (r.stdout + r.stderr), r.stdout + r.stderr  # -Wall -Wextra (-pedantic for the C99 one)
     r = run([os.path.join(EX, "render_c")])
     assert r.returncode == 0 and "spp 5, max_bounces 20" in r.stdout, r.stdout + r.stderr
@@ -47,6 +52,7 @@ def test_c_host_renders_what_the_python_path_renders(tmp_path):
     from helpers import gpu_frames
     from raytracer_amd.renderer import Context, Scene
 
+    build_examples()  # gcc only, a no-op when build() has run
     out = tmp_path / "c.ppm"
     r = run([os.path.join(EX, "render_c"), "1", "64", "36", "2", "4", "2", str(out)])
     assert r.returncode == 0, r.stdout + r.stderr
@@ -63,5 +69,6 @@ def test_c_host_renders_what_the_python_path_renders(tmp_path):
 
 @pytest.mark.gpu
 def test_cpp_binding_with_application_owned_vectors():
+    build_examples()
     r = run([os.path.join(EX, "hip_backend"), "run"])
     assert r.returncode == 0 and "identical" in r.stdout, r.stdout + r.stderr
