@@ -216,12 +216,15 @@ def main() -> None:
         achieved_tflops = launch_flops / (avg_kernel_ms * 1e-3) / 1e12
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_passes.sh) of
         # this workload on one GPU; bench.py cannot run the profiler on itself.
-        traffic, traffic_note = None, None
+        traffic, traffic_note, issue = None, None, {}
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"{args.workload}:{pipeline}")
             if rec and world == 1 and args.accel == "bvh":
                 traffic = (rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024.0
                 traffic_note = rec["note"]
+                # from the same passes: share of the SIMDs' time with a vector instruction in flight (about 1 =
+                # the vector pipes are saturated) and the share of lanes active in those instructions
+                issue = {k: rec[k] for k in ("valu_active_frac", "lane_utilisation", "l2_hit") if k in rec}
         except (OSError, ValueError, KeyError):
             pass
         result = {
@@ -260,6 +263,7 @@ def main() -> None:
                 "prim_tests_per_ray": tests_per_ray,
                 "algorithmic_GBps": launch_bytes / (avg_kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
+                **issue,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
