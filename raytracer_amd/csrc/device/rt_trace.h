@@ -293,12 +293,15 @@ RT_DEV bool slot_to_pixel(const FrameArgs& fa, uint32_t slot, int& x, int& y) {
     return true;
 }
 
-// A finished pixel reports what it cost (path segments over all its samples) to its image block.
+// A finished pixel reports what it cost (path segments over all its samples) to its image block,
+// which keeps the largest: a block is as urgent as its longest pixel, because the frame cannot
+// end before a pixel that started late has walked its whole chain of samples (ordering blocks by
+// the sum of their pixels' costs instead left C3 2 % and the 1 M-triangle scene 7 % slower).
 RT_DEV void report_pixel_cost(const FrameArgs& fa, int x, int y, uint32_t cost) {
     if (fa.tile_cost == nullptr) return;
     int r = y;
     if (fa.strip_rows > 0) r = ((y / fa.strip_rows) / fa.strip_count) * fa.strip_rows + (y % fa.strip_rows);
-    atomicAdd(&fa.tile_cost[(uint32_t)(r >> kBlockPixLog2) * (uint32_t)fa.tiles_x + (uint32_t)(x >> kBlockPixLog2)], cost);
+    atomicMax(&fa.tile_cost[(uint32_t)(r >> kBlockPixLog2) * (uint32_t)fa.tiles_x + (uint32_t)(x >> kBlockPixLog2)], cost);
 }
 
 // The second half of sample_light (raytracer.comp:617-626, 636-644, 662-671): what arrives
