@@ -357,6 +357,9 @@ int rt_controller_end_frame(RtController* c, double now_seconds);
  * exactly one leaf, boxes nested, depth within the traversal limit; RT_ERR_UNSUPPORTED if
  * not) and reports node count, depth, primitive count and SAH cost. */
 int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost);
+/* Fingerprint (FNV-1a) of the node array and leaf order rt_upload_scene would build for this scene:
+ * the build is deterministic, whatever the number of host threads it uses. */
+int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash);
 
 #ifdef __cplusplus
 }

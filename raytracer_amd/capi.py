@@ -185,6 +185,7 @@ PROTOTYPES = {
     "rt_controller_end_frame": (C.c_int, [_P, C.c_double]),
     "rt_scene_bvh_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_float)]),
+    "rt_scene_bvh_hash": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

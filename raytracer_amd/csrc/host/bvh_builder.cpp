@@ -1,8 +1,14 @@
 // bvh_builder.cpp — binned-SAH binary BVH over spheres, triangles and mesh triangles.
+// Large scenes are built in parallel: the top of the tree serially down to subtrees of a fixed size
+// (a function of the primitive count only), the subtrees by a pool of threads, and the nodes are
+// then laid out exactly as the serial depth-first build would lay them out, so the result does not
+// depend on the number of threads.
 #include "bvh_builder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -73,14 +79,22 @@ Box prim_box(const PrimRecord& p) {
 }
 
 struct ChildRef {
-    int32_t index;
+    int32_t index;  // node or first primitive; -1: empty slot; <= -2: subtree task -2 - index (parallel build only)
     int32_t count;
     Box box;
+};
+
+struct SubtreeTask {
+    int begin, end, depth;
 };
 
 class Builder {
 public:
     Builder(std::vector<BuildPrim>& prims, HostBvh& out) : prims_(prims), out_(out) {}
+
+    // Subtrees of at most this many primitives (below the root) are not built but recorded in `tasks`.
+    int defer_at_most = 0;
+    std::vector<SubtreeTask> tasks;
 
     static int max_leaf() {
         static int v = [] { const char* e = getenv("RT_MAX_LEAF"); int x = e ? atoi(e) : 4; return (x >= 1 && x <= 8) ? x : 4; }();
@@ -96,6 +110,14 @@ public:
             cbox.grow(prims_[i].centroid);
         }
         int n = end - begin;
+        if (depth > 0 && n <= defer_at_most && n > 1) {
+            ChildRef ref;
+            ref.index = -2 - (int32_t)tasks.size();
+            ref.count = 0;
+            ref.box = box;
+            tasks.push_back({begin, end, depth});
+            return ref;
+        }
         out_.depth = std::max(out_.depth, depth);
         if (n <= 1) return leaf(begin, end, box);
 
@@ -225,6 +247,43 @@ bool fail(std::string* err, const std::string& m) {
     return false;
 }
 
+struct SubtreeResult {
+    HostBvh bvh;      // nodes with indices local to the subtree (its root, if internal, is node 0)
+    ChildRef root;
+    float sah = 0.0f, leaf_sah = 0.0f;
+};
+
+// Copies the serially built top of the tree and the subtrees into `out` in depth-first order.
+int32_t emit_node(const std::vector<BvhNode>& top, int32_t t, const std::vector<SubtreeResult>& sub, std::vector<BvhNode>& out) {
+    const int32_t me = (int32_t)out.size();
+    out.push_back(top[t]);
+    for (int c = 0; c < 2; ++c) {
+        const int32_t child = c == 0 ? top[t].child0 : top[t].child1;
+        const int32_t count = c == 0 ? top[t].count0 : top[t].count1;
+        int32_t new_child = child, new_count = count;
+        if (count == 0 && child >= 0) {
+            new_child = emit_node(top, child, sub, out);
+        } else if (count == 0 && child <= -2) {
+            const SubtreeResult& r = sub[(size_t)(-2 - child)];
+            if (r.root.count > 0) {
+                new_child = r.root.index;
+                new_count = r.root.count;
+            } else {
+                const int32_t base = (int32_t)out.size();
+                for (BvhNode nd : r.bvh.nodes) {
+                    if (nd.count0 == 0 && nd.child0 >= 0) nd.child0 += base;
+                    if (nd.count1 == 0 && nd.child1 >= 0) nd.child1 += base;
+                    out.push_back(nd);
+                }
+                new_child = base + r.root.index;
+            }
+        }
+        if (c == 0) { out[me].child0 = new_child; out[me].count0 = new_count; }
+        else        { out[me].child1 = new_child; out[me].count1 = new_count; }
+    }
+    return me;
+}
+
 }  // namespace
 
 bool gather_primitives(const SceneArrays& s, std::vector<PrimRecord>& out, std::string* err) {
@@ -308,7 +367,37 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
         out.nodes.emplace_back();
         b.set_children(0, empty, empty);
     } else {
-        ChildRef root = b.build(0, (int)bp.size(), 0);
+        // subtrees of up to 1/64 of the scene (at least 8192 primitives) are built by other threads
+        const int n_all = (int)bp.size();
+        if (n_all >= 65536 && !getenv("RT_BVH_SERIAL")) b.defer_at_most = std::max(8192, n_all / 64);  // the variable: testing aid
+        ChildRef root = b.build(0, n_all, 0);
+        if (!b.tasks.empty()) {
+            std::vector<SubtreeResult> sub(b.tasks.size());
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (size_t k = next.fetch_add(1); k < b.tasks.size(); k = next.fetch_add(1)) {
+                    Builder sb(bp, sub[k].bvh);
+                    sub[k].root = sb.build(b.tasks[k].begin, b.tasks[k].end, b.tasks[k].depth);
+                    sub[k].sah = sb.sah_;
+                    sub[k].leaf_sah = sb.leaf_sah_;
+                }
+            };
+            unsigned n_threads = std::thread::hardware_concurrency();
+            n_threads = std::max(1u, std::min({n_threads, 16u, (unsigned)b.tasks.size()}));
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work);
+            work();
+            for (std::thread& t : pool) t.join();
+            std::vector<BvhNode> top;
+            top.swap(out.nodes);
+            emit_node(top, 0, sub, out.nodes);
+            for (const SubtreeResult& r : sub) {
+                out.depth = std::max(out.depth, r.bvh.depth);
+                out.max_leaf = std::max(out.max_leaf, r.bvh.max_leaf);
+                b.sah_ += r.sah;
+                b.leaf_sah_ += r.leaf_sah;
+            }
+        }
         if (root.count > 0 || out.nodes.empty()) {
             // the whole scene fits one leaf: wrap it so that node 0 is always an internal node
             out.nodes.clear();

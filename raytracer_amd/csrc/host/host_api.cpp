@@ -197,4 +197,28 @@ int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_
     return RT_OK;
 }
 
+// FNV-1a over the BVH's node array and leaf order (what rt_upload_scene would copy to the device).
+int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash) {
+    if (!s || !hash) return RT_ERR_INVALID_ARGUMENT;
+    const Scene& sc = s->scene;
+    rt::SceneArrays a;
+    a.spheres = sc.sphereVec.data();     a.n_spheres = sc.total_spheres;
+    a.triangles = sc.triangleVec.data(); a.n_triangles = sc.total_triangles;
+    a.vertices = sc.vertexVec.data();    a.n_vertices = (int32_t)sc.vertexVec.size();
+    a.indices = sc.indexVec.data();      a.n_indices = (int32_t)sc.indexVec.size();
+    a.meshes = sc.meshVec.data();        a.n_meshes = sc.total_meshes;
+    rt::HostBvh bvh;
+    std::string err;
+    if (!rt::build_bvh(a, bvh, &err)) return RT_ERR_INVALID_ARGUMENT;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode));
+    mix(bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
+    *hash = h;
+    return RT_OK;
+}
+
 }  // extern "C"

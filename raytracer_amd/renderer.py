@@ -121,6 +121,11 @@ class Scene:
         self._chk(self._lib.rt_scene_bvh_info(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(s)), "rt_scene_bvh_info")
         return {"nodes": n.value, "depth": d.value, "prims": p.value, "sah_cost": s.value}
 
+    def bvh_hash(self) -> int:
+        h = C.c_uint64()
+        self._chk(self._lib.rt_scene_bvh_hash(self._h, C.byref(h)), "rt_scene_bvh_hash")
+        return h.value
+
 
 def default_camera(width: int, height: int) -> capi.RtCamera:
     cam = capi.RtCamera()

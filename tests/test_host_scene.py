@@ -132,3 +132,21 @@ def test_scene_buffer_hashes_are_pinned():
         arrays = Scene(preset).arrays()
         got = {k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in arrays.items()}
         assert got == want[name], name
+
+
+def test_parallel_bvh_build_lays_the_tree_out_as_the_serial_build_does(monkeypatch):
+    """Scenes of 65 536 primitives or more build their subtrees on several threads; nodes and leaf
+    order must come out exactly as from the serial depth-first build (RT_BVH_SERIAL forces that)."""
+    import time
+    s = Scene(capi.RT_SCENE_TEAPOT_GRID)
+    t0 = time.perf_counter()
+    parallel = s.bvh_hash()
+    t1 = time.perf_counter()
+    info = s.bvh_info()  # validates the structure
+    monkeypatch.setenv("RT_BVH_SERIAL", "1")
+    t2 = time.perf_counter()
+    serial = s.bvh_hash()
+    t3 = time.perf_counter()
+    assert parallel == serial
+    assert info["prims"] > 1_000_000
+    print(f"1.07 M triangles: parallel build {t1 - t0:.2f} s, serial {t3 - t2:.2f} s")
