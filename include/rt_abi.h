@@ -262,7 +262,9 @@ enum { RT_SCENE_EMPTY = 0,
        RT_SCENE_CORNELL_STAR = 1,   /* Scene::createCornellBox verbatim (scene.cpp:350-695)    */
        RT_SCENE_PRESET1 = 2,        /* Scene::createPreset1 (scene.cpp:37-348)                  */
        RT_SCENE_CORNELL_TEAPOT = 3, /* Cornell box with teapot.glb in place of star.glb         */
-       RT_SCENE_TEAPOT_GRID = 4 };  /* 13x13 teapots baked into one mesh (~1.07 M triangles)    */
+       RT_SCENE_TEAPOT_GRID = 4,    /* 13x13 teapots baked into one mesh (~1.07 M triangles)    */
+       RT_SCENE_PRESET1_TEAPOT = 5 }; /* createPreset1 with the teapot it defines but leaves out
+                                       (scene.cpp:333-343: blue matte, pitch 90, at (0,-1,10))   */
 
 int rt_scene_create(int preset, const char* assets_dir, RtScene** out);
 int rt_scene_destroy(RtScene* s);

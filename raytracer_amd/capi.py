@@ -45,6 +45,7 @@ RT_SCENE_CORNELL_STAR = 1
 RT_SCENE_PRESET1 = 2
 RT_SCENE_CORNELL_TEAPOT = 3
 RT_SCENE_TEAPOT_GRID = 4
+RT_SCENE_PRESET1_TEAPOT = 5
 
 RT_LIGHT_AMBIENT, RT_LIGHT_SPHERE, RT_LIGHT_POINT, RT_LIGHT_DIRECTIONAL = 0, 1, 2, 3
 RT_LIGHT_CONE, RT_LIGHT_AREA, RT_LIGHT_TRIANGLE = 4, 5, 6

@@ -27,7 +27,7 @@ void rt_default_params(RtParams* out) {
 }
 
 int rt_scene_create(int preset, const char* assets_dir, RtScene** out) {
-    if (!out || preset < RT_SCENE_EMPTY || preset > RT_SCENE_TEAPOT_GRID) return RT_ERR_INVALID_ARGUMENT;
+    if (!out || preset < RT_SCENE_EMPTY || preset > RT_SCENE_PRESET1_TEAPOT) return RT_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     RtScene* s = new (std::nothrow) RtScene(preset, assets_dir ? assets_dir : "assets/");
     if (!s) return RT_ERR_TOO_LARGE;

@@ -82,7 +82,8 @@ Scene::Scene(int preset, const std::string& assets) : assets_dir(assets) {
 
     switch (preset) {
         case RT_SCENE_CORNELL_STAR: createCornellBox(); break;
-        case RT_SCENE_PRESET1: createPreset1(); break;
+        case RT_SCENE_PRESET1: createPreset1(false); break;
+        case RT_SCENE_PRESET1_TEAPOT: createPreset1(true); break;
         case RT_SCENE_CORNELL_TEAPOT: createCornellTeapot(); break;
         case RT_SCENE_TEAPOT_GRID: createTeapotGrid(); break;
         default: break;
@@ -397,7 +398,7 @@ static const MatRow kPreset1Materials[15] = {
 enum { pGround = 0, pRedMatte, pGold, pBlueLight, pCloudyGlass, pBlueMatte, pRedMetal, pYellowMetal, pDielectric075,
        pDielectric133, pGlass, pMirror, pWhiteLight, pBlueLight2, pWarmLight };
 
-void Scene::createPreset1() {
+void Scene::createPreset1(bool with_teapot) {
     for (const auto& row : kPreset1Materials) addMaterial(material_from(row));
     static const struct { float x, y, z, r; int mat; } spheres[13] = {
         {0.0f, -1000.0f, -10.0f, 999.0f, pGround},
@@ -417,6 +418,10 @@ void Scene::createPreset1() {
     for (const auto& s : spheres) addSphere(make_sphere(s.x, s.y, s.z, s.r, s.mat));
     addTriangle(make_tri(rtm::v3(0.0f, -1.0f, -5.0f), rtm::v3(2.5f, 2.0f, -5.0f), rtm::v3(-2.5f, 2.0f, -5.0f), pBlueMatte));
     addTriangle(make_tri(rtm::v3(0.0f, -1.0f, -15.0f), rtm::v3(2.5f, 2.0f, -15.0f), rtm::v3(-2.5f, 2.0f, -15.0f), pBlueMatte));
+    if (with_teapot) {  // the model scene.cpp:333-341 defines; its addModel call (343) is commented out there
+        Model teapot{"teapot.glb", rtm::v3(0.0f, -1.0f, 10.0f), /*pitch*/ 90.0f, /*yaw*/ 0.0f, /*roll*/ 0.0f, 1.0f, pBlueMatte};
+        addModel(teapot);
+    }
     printSceneInfo();
 }
 

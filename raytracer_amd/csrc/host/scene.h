@@ -48,7 +48,7 @@ public:
     // preset is a parameter.  RT_SCENE_EMPTY leaves only the placeholder elements.
     explicit Scene(int preset = RT_SCENE_CORNELL_STAR, const std::string& assets = "assets/");
 
-    void createPreset1();       // scene.cpp:37-348
+    void createPreset1(bool with_teapot);  // scene.cpp:37-348; the teapot of 333-343 is optional as there
     void createCornellBox();    // scene.cpp:350-695
     void createCornellTeapot(); // Cornell box geometry with teapot.glb instead of star.glb
     void createTeapotGrid();    // 13 x 13 teapots baked into one mesh, rebased indices

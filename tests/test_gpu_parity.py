@@ -13,7 +13,7 @@ import pytest
 
 from helpers import bit_equal_pixels, gpu_frames, oracle_frames
 from raytracer_amd import capi
-from raytracer_amd.renderer import Context, Controller, Scene, make_params
+from raytracer_amd.renderer import Context, Controller, Scene, look_camera, make_params
 
 pytestmark = pytest.mark.gpu
 
@@ -154,6 +154,24 @@ def test_light_types_transparency_and_transmission(ctx, kind, accel):
     else:
         assert_identical_but_edge_ties(g, o)
     assert np.isfinite(g["accum"]).all()
+
+
+@pytest.mark.parametrize("preset,front", [(capi.RT_SCENE_PRESET1, (0, 0, -1)), (capi.RT_SCENE_PRESET1_TEAPOT, (0, 0, 1)),
+                                          (capi.RT_SCENE_PRESET1_TEAPOT, (0, -0.2, -1))])
+@pytest.mark.parametrize("accel", [capi.RT_ACCEL_FLAT, capi.RT_ACCEL_BVH])
+def test_preset1_from_inside_the_scene(ctx, preset, front, accel):
+    """createPreset1 (sphere-heavy: mirrors, nested dielectrics, an emissive sphere and triangles) and its
+    variant with the teapot, seen from the origin towards the spheres (-z) and towards the teapot (+z)."""
+    s = Scene(preset)
+    W, H = 96, 54
+    cam = look_camera((0.0, 0.5, 0.0), front, (0, 1, 0), 60.0, W, H)
+    o = oracle_frames(s, W, H, spp=2, max_bounces=6, camera=cam)
+    g = gpu_frames(ctx, s, W, H, spp=2, max_bounces=6, accel=accel, camera=cam)
+    if accel == capi.RT_ACCEL_FLAT:
+        assert_identical(g, o)
+    else:
+        assert_identical_but_edge_ties(g, o)
+    assert len(np.unique(g["primary_ids"])) > 3  # the camera does see the scene
 
 
 @pytest.mark.parametrize("skybox", [capi.RT_SKY_DAY, capi.RT_SKY_NIGHT, capi.RT_SKY_WHITE, capi.RT_SKY_BLACK])

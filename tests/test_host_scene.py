@@ -121,6 +121,25 @@ def test_bvh_structure_of_every_preset():
         assert info["prims"] == prims and 1 <= info["depth"] <= 30
 
 
+def test_preset1_with_the_teapot_the_reference_leaves_commented_out():
+    """scene.cpp:333-343 defines a teapot for createPreset1 and comments its addModel call out;
+    RT_SCENE_PRESET1_TEAPOT makes that call: everything else is createPreset1 unchanged."""
+    plain, pot = Scene(capi.RT_SCENE_PRESET1), Scene(capi.RT_SCENE_PRESET1_TEAPOT)
+    a, b = plain.arrays(), pot.arrays()
+    for k in ("spheres", "materials", "lights", "triangles"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    vp, vt = plain.view(), pot.view()
+    assert (vp.total_meshes, vt.total_meshes) == (0, 1)
+    assert vt.n_vertices == 18960 and vt.n_indices == 18960
+    start, end, material = np.frombuffer(b["meshes"].tobytes(), dtype=np.int32)[:3]
+    assert (int(start), int(end)) == (0, 18960) and 0 <= int(material) < vt.n_materials
+    info = pot.bvh_info()
+    assert info["prims"] == 15 + 6320
+    # pitch 90 about x, scale 1, moved to (0, -1, 10): the model's bounds sit around that point
+    v = b["vertices"].view(np.float32).reshape(-1, 4)[:, :3]
+    assert abs(float(v[:, 0].mean())) < 1.5 and 5.0 < float(v[:, 2].mean()) < 15.0
+
+
 def test_scene_buffer_hashes_are_pinned():
     """Golden: sha256 of the seven buffers of the default scenes (tests/golden/scene_hashes.json)."""
     import hashlib
