@@ -65,9 +65,9 @@ def main() -> None:
     ap.add_argument("--partition", default=None, choices=["strips", "samples"],
                     help="how N GPUs share the work: row strips of every frame (default) or whole frames "
                          "(sample sharding, default for c4)")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled", "staged"],
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled"],
                     help="schedule of the per-path program (same results): the library's own choice, the single "
-                         "persistent kernel, the pooled kernel (LDS queues), or one launch per stage")
+                         "persistent kernel, or the pooled kernel (LDS queues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
@@ -103,8 +103,7 @@ def main() -> None:
     partition = args.partition or ("samples" if args.workload == "c4" else "strips")
     frames_per_step = FRAMES_PER_BATCH if partition == "samples" else 1
     strip = (STRIP_ROWS, world, rank) if (collective and partition == "strips") else (0, 1, 0)
-    pipe_flags = {"auto": 0, "single": capi.RT_FLAG_SINGLE_KERNEL, "pooled": capi.RT_FLAG_POOLED,
-                  "staged": capi.RT_FLAG_WAVEFRONT}[args.pipeline]
+    pipe_flags = {"auto": 0, "single": capi.RT_FLAG_SINGLE_KERNEL, "pooled": capi.RT_FLAG_POOLED}[args.pipeline]
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], pipe_flags)
     rt_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     main_stream = torch.cuda.current_stream(dev)
@@ -186,7 +185,7 @@ def main() -> None:
     avg_kernel_ms = float(kern.item())
 
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
-    pipeline = ["single", "staged", "pooled"][ctx.stats().pipeline]  # what the timed frames ran on
+    pipeline = {capi.RT_PIPELINE_SINGLE: "single", capi.RT_PIPELINE_POOLED: "pooled"}[ctx.stats().pipeline]  # what the timed frames ran on
     flags = capi.RT_FLAG_TRAVERSAL_STATS | pipe_flags
     pc = scene.push_constants(0.0, SETTLE + args.warmup, False)
     ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
@@ -249,7 +248,7 @@ def main() -> None:
                        "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
             "roofline": {
                 "bound": "valu",
-                "kernel": {"single": "render_kernel", "pooled": "pool_kernel", "staged": "wf_search_kernel + wf_shade_kernel"}[pipeline],
+                "kernel": {"single": "render_kernel", "pooled": "pool_kernel"}[pipeline],
                 "achieved": achieved_tflops,
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",

@@ -26,7 +26,7 @@ typedef enum RtStatus {
     RT_ERR_HIP = -2,            /* a HIP runtime call failed; see rt_last_error()            */
     RT_ERR_NO_SCENE = -3,       /* render requested before rt_upload_scene                    */
     RT_ERR_NO_FRAMEBUFFER = -4, /* render requested before rt_resize / rt_bind_framebuffer    */
-    RT_ERR_UNSUPPORTED = -5,    /* e.g. POINT/CONE/AREA lights: undefined in the reference    */
+    RT_ERR_UNSUPPORTED = -5,    /* not a gfx950 device; a BVH the traversal cannot walk; a retired flag */
     RT_ERR_IO = -6,             /* asset file missing / malformed                             */
     RT_ERR_TOO_LARGE = -7
 } RtStatus;
@@ -139,9 +139,8 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
        RT_FLAG_PATH_HASH   = 2u,   /* record a hash of every nearest-hit id along the paths    */
        RT_FLAG_COUNT_RAYS  = 4u,   /* accepted, no effect: rays are always counted             */
        RT_FLAG_TRAVERSAL_STATS = 8u, /* count BVH nodes visited / primitives tested            */
-       RT_FLAG_WAVEFRONT   = 16u,  /* staged pipeline: one search launch + one shading launch
-                                      per ray generation instead of the single persistent kernel;
-                                      same results                                              */
+       RT_FLAG_RESERVED_16 = 16u,  /* selected a pipeline of one launch per stage that was measured,
+                                      lost everywhere and was removed; refused with RT_ERR_UNSUPPORTED */
        RT_FLAG_POOLED      = 32u,  /* pooled pipeline: one persistent launch whose workgroups keep
                                       two paths per lane, their hot state in LDS, and regroup them
                                       by kind of work through queues in LDS; same results         */
@@ -149,11 +148,12 @@ enum { RT_FLAG_PRIMARY_IDS = 1u,   /* record sample-0 primary-hit primitive id p
        RT_FLAG_FIXED_TILE_ORDER = 128u /* hand the image's 8x8 tiles out in image order instead of
                                       dearest-first as measured on the previous frame of the same
                                       size; same results, only the schedule differs              */ };
-/* With none of RT_FLAG_WAVEFRONT / RT_FLAG_POOLED / RT_FLAG_SINGLE_KERNEL the library chooses: with
- * the BVH and at least 16384 pixels it times the pooled kernel (third frame of a configuration)
- * against the single kernel (fifth frame) and keeps the faster from the sixth frame on; otherwise the single kernel.
- * All pipelines give the same bits. */
-enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_STAGED = 1, RT_PIPELINE_POOLED = 2 };
+/* With neither RT_FLAG_POOLED nor RT_FLAG_SINGLE_KERNEL the library chooses: with the BVH and at
+ * least 16384 pixels it times the pooled kernel (third frame of a configuration) against the single
+ * kernel (fifth frame) and runs the faster from the sixth frame on (pooled while a timing is still
+ * outstanding: the events are polled, never waited for); otherwise the single kernel.
+ * Both pipelines give the same bits. */
+enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_POOLED = 2 };
 
 typedef struct RtStats {
     uint64_t rays;          /* nearest-hit searches in the last frame (always counted)         */
@@ -219,7 +219,11 @@ int rt_bind_framebuffer(RtContext* ctx, int32_t width, int32_t height,
 /* One reference frame: updateUniformBuffer + push constants + vkCmdDispatch
  * (main.cpp:1466-1497, 1424-1438, 1234-1241) = one execution of raytracer.comp::main per
  * pixel (raytracer.comp:956-996), including reset_frame_accumulation and the accumulate /
- * BGRA8 store.  Asynchronous on the context's stream. params == NULL: reference defaults. */
+ * BGRA8 store.  Asynchronous on the context's stream: it enqueues and returns, except that the
+ * first frame of a new size / partition / pipeline may allocate scratch memory (which waits for the
+ * stream).  params == NULL: reference defaults.  A frame the pooled kernel had to abandon (a bound
+ * on waiting inside a workgroup was exceeded; never seen in a correct run) is reported by the next
+ * rt_sync / rt_read_* / rt_get_stats as RT_ERR_HIP. */
 int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pc,
                     const RtParams* params);
 
@@ -243,6 +247,17 @@ int rt_read_debug(RtContext* ctx, int32_t* primary_ids, uint32_t* path_hash);
 int rt_debug_math(RtContext* ctx, int fn, const float* x, const float* y, float* out, int32_t n);
 
 int rt_get_stats(RtContext* ctx, RtStats* out);
+
+/* Tuning knobs with no counterpart in the reference.  Results never depend on them, only the
+ * schedule (and for RT_OPT_BVH_MAX_LEAF the shape of the tree built by the NEXT rt_upload_scene). */
+enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once this % of busy lanes have a result (1..100, 75) */
+       RT_OPT_REFILL_MIN = 2,     /* pooled kernel: idle lanes of a searching wave before it fetches new rays (1..64, 16)      */
+       RT_OPT_POOL_BURST = 3,     /* pooled kernel: search steps between two looks at the queues (1..1024, 16)                */
+       RT_OPT_POOL_JOB_MIN = 4,   /* pooled kernel: queue entries that make a shading job (1..64, 64)                        */
+       RT_OPT_TILE_CLASSES = 5,   /* cost classes of the frame-to-frame tile order (1..64, 16)                               */
+       RT_OPT_POOL_PER_CU = 6,    /* pooled kernel: cap on workgroups per CU (0 = what fits, ..8)                            */
+       RT_OPT_BVH_MAX_LEAF = 7 }; /* most primitives per BVH leaf (1..8, 4)                                                  */
+int rt_set_option(RtContext* ctx, int option, int value);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);
 /* The context's hipStream_t. */

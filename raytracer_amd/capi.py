@@ -32,13 +32,15 @@ RT_FLAG_PRIMARY_IDS = 1
 RT_FLAG_PATH_HASH = 2
 RT_FLAG_COUNT_RAYS = 4
 RT_FLAG_TRAVERSAL_STATS = 8
-RT_FLAG_WAVEFRONT = 16
+RT_FLAG_RESERVED_16 = 16
 RT_FLAG_POOLED = 32
 RT_FLAG_SINGLE_KERNEL = 64
 RT_FLAG_FIXED_TILE_ORDER = 128
 RT_MODEL_FULL_GLTF, RT_MODEL_REBASE_INDICES = 1, 2
 RT_SKY_GREY, RT_SKY_DAY, RT_SKY_NIGHT, RT_SKY_WHITE, RT_SKY_BLACK = 0, 1, 2, 3, 4
-RT_PIPELINE_SINGLE, RT_PIPELINE_STAGED, RT_PIPELINE_POOLED = 0, 1, 2
+RT_PIPELINE_SINGLE, RT_PIPELINE_POOLED = 0, 2
+RT_OPT_EXIT_QUOTA_PCT, RT_OPT_REFILL_MIN, RT_OPT_POOL_BURST, RT_OPT_POOL_JOB_MIN = 1, 2, 3, 4
+RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF = 5, 6, 7
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1
@@ -150,6 +152,7 @@ PROTOTYPES = {
     "rt_read_debug": (C.c_int, [_P, _P, _P]),
     "rt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int32]),
     "rt_get_stats": (C.c_int, [_P, C.POINTER(RtStats)]),
+    "rt_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "rt_get_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "rt_get_stream": (_P, [_P]),
     "rt_sync": (C.c_int, [_P]),

@@ -40,7 +40,6 @@ struct FrameArgs {
     uint32_t flags;
     int32_t exit_quota_pct;  // the search loop returns once this share of the wave's busy lanes has finished
     int32_t accel;           // RT_ACCEL_*: which record array the search results index
-    int32_t stack_depth;     // entries per traversal stack (staged pipeline: sized to the scene's BVH)
     int32_t skybox;          // RT_SKY_*
     // outputs
     float4* accum;
@@ -53,8 +52,11 @@ struct FrameArgs {
     // per frame): [10..15] wave cycles in refill+raygen / search / shading, [16..17] per-lane traversal
     // iterations, [18..19] per-wave traversal iterations, [20..29] wave cycles of the five parts of
     // the continuation (pooled pipeline: [20..27] items << 32 | jobs per shading queue, [28..29] deep
-    // stack pushes, [30] abort flag, [32..39] wave cycles per shading queue)
+    // stack pushes, [32..39] wave cycles per shading queue)
     uint32_t* counters;
+    // Set to 1 (never cleared by a kernel) when the pooled kernel gave up waiting inside a workgroup and the
+    // frame is incomplete; host-visible memory, so that the host sees it after a plain stream synchronise.
+    uint32_t* abort_flag;
     // Order in which the image's pixel blocks are handed out: slot block k renders image block
     // tile_order[k] (null: k itself).  tile_cost (may be null) receives, per image block, the path
     // segments traced for it this frame; the next frame's order is made from it.
@@ -70,8 +72,7 @@ enum { kBlock = 256, kStackDepth = 32 };
 #endif
 enum { kBlockTilesLog2 = RT_BLOCK_TILES_LOG2, kBlockPixLog2 = 3 + kBlockTilesLog2, kBlockSlotsLog2 = 2 * kBlockPixLog2 };
 
-// Path state of the staged pipeline: one slot per pixel in flight, structure of arrays in
-// device memory.  `stage` says what a slot waits for between launches.
+// What a slot of the pooled pipeline waits for (the kind bits of a queue entry are derived from it).
 enum : uint32_t {
     WF_IDLE = 0,          // no path (pixel finished, or slot outside the image)
     WF_PATH_FIRST = 1,    // path ray at bounce 0 awaits the nearest-hit search
@@ -81,43 +82,36 @@ enum : uint32_t {
     WF_LIGHT_UNDEF = 5,   // light picked, no search needed: the shader's undefined light types
     WF_PATH_NEXT = 6      // path ray at bounce > 0 awaits the search
 };
+// Device memory of the pooled pipeline (its hot path state lives in LDS): per slot 4 float4 of cold
+// state (pixel sum | normal, light distance | path direction, light index | material bits), per lane an
+// overflow area for traversal stack entries beyond those kept in LDS.
 struct PathPool {
-    uint32_t* stage;
-    uint4* ctl;     // RNG state, pixel index (y * width + x), sample, bounce
-    float4* ray_o;  // origin of the ray handed to the search; w = distance to the sampled light point
-    float4* ray_d;  // its direction; w (bits) = index of the picked light
-    uint2* hit;     // search result: t (bits), primitive record index (-1: none)
-    float4* att;    // path attenuation; w (bits) = hash of the nearest-hit ids so far
-    float4* col;    // radiance of the current sample
-    float4* pix;    // sum of this pixel's finished samples
-    float4* hp;     // shading point kept across a light query; w (bits) = material | front_face << 31
-    float4* hn;     // shading normal kept across a light query
-    float4* vdir;   // direction of the path ray that reached the shading point
-    uint32_t* active;  // [iterations + 1] slots still in flight at the start of each iteration
-    uint32_t n_slots;
-    // pooled pipeline (hot state in LDS): per slot 4 float4 of cold state (pixel sum | normal, light
-    // distance | path direction, light index | material bits), per lane an overflow area for
-    // traversal stack entries beyond those kept in LDS
     float4* cold;
     uint32_t* stack_overflow;
+    uint32_t n_slots;
 };
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
                          hipStream_t stream);
-// The staged pipeline: generate, then `iterations` x (search launch, shading launch).
-hipError_t launch_wavefront(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, int iterations,
-                            int refill_min, int cu_count, hipStream_t stream);
 // The pooled pipeline: one persistent launch, path slots regrouped through LDS queues.
 int pool_slots_per_block();
 int pool_overflow_per_lane();
 int pool_threads_per_block();
-hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, unsigned* grid);
+// per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid)
+hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
                        int refill_min, int burst, int job_min, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 // Turns the per-tile costs of the frame just rendered into the next frame's tile order (most
-// expensive class first, image order within a class) and clears the costs.
-hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, hipStream_t stream);
+// expensive class first, image order within a class) and clears the costs.  At most
+// tile_order_max_tiles() tiles.  `stamp` (may be null): 8 words that receive `key` once the order is
+// written, so that a later launch_tile_order_check can tell what the order was made for.
+uint32_t tile_order_max_tiles();
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* stamp,
+                             const uint32_t key[8], hipStream_t stream);
+// Replaces tile_order by the identity unless `stamp` holds `key` (device-side check: no host state).
+hipError_t launch_tile_order_check(uint32_t* tile_order, uint32_t n_tiles, const uint32_t* stamp, const uint32_t key[8],
+                                   hipStream_t stream);
 hipError_t launch_resolve(float4* accum, int32_t* counts, uint32_t* bgra, int n_pixels, hipStream_t stream);
 
 }  // namespace rtd

@@ -531,81 +531,130 @@ hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, 
 namespace {
 
 constexpr int kOrderThreads = 1024;
+constexpr int kOrderWaves = kOrderThreads / 64;
 constexpr int kMaxClasses = 64;
+constexpr uint32_t kOrderMaxTiles = 128u * 1024u;  // one class byte per tile in LDS
 
-// Exclusive prefix sum of one value per thread over the workgroup (kOrderThreads threads).
-RT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(inc, off);
-        if (lane >= off) inc += up;
-    }
-    __syncthreads();  // s_wave may still be read from the previous call
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int w = 0; w < kOrderThreads / 64; ++w) {
-        const uint32_t t = s_wave[w];
-        if (w < wave) before += t;
-        all += t;
-    }
-    total = all;
-    return before + inc - v;
-}
-
-// One workgroup.  Tiles are put into `classes` classes by cost relative to the dearest tile and
-// listed class by class, dearest first, in image order within a class (neighbouring tiles stay
-// neighbours: their rays share nodes and materials).  Long pixels thus start early and the
+// One workgroup, three sweeps.  Tiles are put into `classes` classes by cost relative to the dearest
+// tile and listed class by class, dearest first, in image order within a class (neighbouring tiles
+// stay neighbours: their rays share nodes and materials).  Long pixels thus start early and the
 // frame ends on short ones.  The costs are cleared for the next frame.
+//   sweep 1: the dearest tile (coalesced loads, many in flight);
+//   sweep 2: every tile's class into LDS (one byte per tile);
+//   sweep 3, twice: each wave walks a contiguous range of tiles 64 at a time and ranks the lanes of
+//            each class present with one ballot - first to count (per wave and class), then, after
+//            one scan of the kOrderWaves x classes counts, to place.
 __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n,
-                                                                   int classes) {
+                                                                   int classes, uint32_t* __restrict__ stamp, const uint32_t k0,
+                                                                   const uint32_t k1, const uint32_t k2, const uint32_t k3, const uint32_t k4,
+                                                                   const uint32_t k5, const uint32_t k6, const uint32_t k7) {
+    extern __shared__ uint8_t s_class[];                     // [n]
     __shared__ uint32_t s_max;
-    __shared__ uint32_t s_wave[kOrderThreads / 64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (n + kOrderThreads - 1) / kOrderThreads;
-    const uint32_t begin = tid * chunk < n ? tid * chunk : n;
-    const uint32_t end = begin + chunk < n ? begin + chunk : n;
+    __shared__ uint32_t s_count[kMaxClasses * kOrderWaves];  // [class][wave]: tiles of the class in the wave's range, then their first position
+    __shared__ uint32_t s_wave[kOrderWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_max = 0;
+    for (uint32_t e = tid; e < (uint32_t)(kMaxClasses * kOrderWaves); e += kOrderThreads) s_count[e] = 0;
     __syncthreads();
     uint32_t m = 0;
-    for (uint32_t i = begin; i < end; ++i) m = cost[i] > m ? cost[i] : m;
-    atomicMax(&s_max, m);
+#pragma unroll 8
+    for (uint32_t i = tid; i < n; i += kOrderThreads) m = cost[i] > m ? cost[i] : m;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
-    const unsigned long long scale = (unsigned long long)s_max + 1ull;
-    uint32_t cnt[kMaxClasses];
-    for (int c = 0; c < kMaxClasses; ++c) cnt[c] = 0;
-    for (uint32_t i = begin; i < end; ++i) {
-        const int c = classes - 1 - (int)(((unsigned long long)cost[i] * (unsigned long long)classes) / scale);
-        for (int k = 0; k < kMaxClasses; ++k) cnt[k] += (k == c) ? 1u : 0u;
-    }
-    uint32_t offs[kMaxClasses];
-    uint32_t base = 0;
-    for (int c = 0; c < kMaxClasses; ++c) {
-        uint32_t total = 0;
-        offs[c] = 0;
-        if (c < classes) {  // uniform across the workgroup
-            offs[c] = base + block_exclusive_scan(cnt[c], s_wave, total);
-            base += total;
-        }
-    }
-    for (uint32_t i = begin; i < end; ++i) {
-        const int c = classes - 1 - (int)(((unsigned long long)cost[i] * (unsigned long long)classes) / scale);
-        uint32_t at = 0;
-        for (int k = 0; k < kMaxClasses; ++k) {
-            if (k == c) { at = offs[k]; offs[k] += 1u; }
-        }
-        order[at] = i;
+    // class = classes - 1 - floor(cost * classes / (max + 1)) in binary32 (monotonic in the cost, which is all
+    // the order needs; an integer division would cost more than the rest of the kernel)
+    const float per_cost = (float)classes / ((float)s_max + 1.0f);
+#pragma unroll 8
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        int c = (int)((float)cost[i] * per_cost);
+        c = c > classes - 1 ? classes - 1 : c;
+        s_class[i] = (uint8_t)(classes - 1 - c);
         cost[i] = 0u;
     }
+    __syncthreads();
+    // a wave's range: whole groups of 64 tiles
+    const uint32_t groups = (n + 63u) / 64u, per_wave = (groups + kOrderWaves - 1u) / kOrderWaves;
+    const uint32_t g_begin = wave * per_wave < groups ? wave * per_wave : groups;
+    const uint32_t g_end = g_begin + per_wave < groups ? g_begin + per_wave : groups;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t g = g_begin; g < g_end; ++g) {
+            const uint32_t i = g * 64u + lane;
+            const int c = i < n ? (int)s_class[i] : -1;
+            unsigned long long left = __ballot(c >= 0);
+            while (left != 0ull) {
+                const int lead = __ffsll((long long)left) - 1;
+                const int cc = __builtin_amdgcn_readlane(c, lead);
+                const unsigned long long same = __ballot(c == cc);
+                uint32_t* const slot = &s_count[cc * kOrderWaves + (int)wave];
+                if (pass == 1) {
+                    const uint32_t at = *(volatile uint32_t*)slot;
+                    if (c == cc) order[at + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+                }
+                if ((int)lane == lead) *(volatile uint32_t*)slot += (uint32_t)__popcll(same);
+                left &= ~same;
+            }
+        }
+        if (pass == 0) {
+            // exclusive scan of s_count in [class][wave] order = first position of each (class, wave) run
+            __syncthreads();
+            const uint32_t v = s_count[tid];
+            uint32_t inc = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(inc, off);
+                if ((int)lane >= off) inc += up;
+            }
+            if (lane == 63u) s_wave[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+            s_count[tid] = before + inc - v;
+            __syncthreads();
+        }
+    }
+    if (stamp != nullptr && tid < 8u) {
+        const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
+        uint32_t v = k[0];
+        for (uint32_t j = 1; j < 8u; ++j) v = (tid == j) ? k[j] : v;
+        stamp[tid] = v;  // read by later launches on the same stream only
+    }
+}
+static_assert(kMaxClasses * kOrderWaves == kOrderThreads, "one thread per (class, wave) count in the scan");
+
+__global__ void __launch_bounds__(256) tile_order_check_kernel(uint32_t* __restrict__ order, uint32_t n, const uint32_t* __restrict__ stamp,
+                                                              const uint32_t k0, const uint32_t k1, const uint32_t k2, const uint32_t k3,
+                                                              const uint32_t k4, const uint32_t k5, const uint32_t k6, const uint32_t k7) {
+    const bool same = stamp[0] == k0 && stamp[1] == k1 && stamp[2] == k2 && stamp[3] == k3 && stamp[4] == k4 && stamp[5] == k5 &&
+                      stamp[6] == k6 && stamp[7] == k7;
+    if (same) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = i;
 }
 
 }  // namespace
 
-hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, hipStream_t stream) {
+uint32_t tile_order_max_tiles() { return kOrderMaxTiles; }
+
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* stamp,
+                             const uint32_t key[8], hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
+    if (n_tiles > kOrderMaxTiles) return hipErrorInvalidValue;
     classes = classes < 1 ? 1 : (classes > kMaxClasses ? kMaxClasses : classes);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, tile_cost, tile_order, n_tiles, classes);
+    static const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t* k = key ? key : zero;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), (size_t)((n_tiles + 15u) & ~15u), stream, tile_cost, tile_order,
+                       n_tiles, classes, stamp, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_order_check(uint32_t* tile_order, uint32_t n_tiles, const uint32_t* stamp, const uint32_t key[8],
+                                   hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_check_kernel, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, tile_order, n_tiles, stamp, key[0],
+                       key[1], key[2], key[3], key[4], key[5], key[6], key[7]);
     return hipGetLastError();
 }
 

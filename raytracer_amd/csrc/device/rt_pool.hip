@@ -10,7 +10,7 @@
 //
 // Why: with one path per lane (rt_kernels.hip) a wave's 64 paths disagree about what to do
 // next, and most vector instructions run with most lanes masked off; with one launch per
-// stage (rt_wavefront.hip) a 1080p frame has too few rays per launch to fill this chip.
+// stage a 1080p frame has too few rays per launch to fill this chip.
 // Here a workgroup keeps kPool paths in flight for its lanes.  Slots that wait for the
 // same kind of work queue up in LDS (search, first-bounce result, later-bounce result,
 // light-query result, sample end); a wave either
@@ -27,8 +27,6 @@
 // Traversal stacks keep kShortStack entries per lane in LDS; deeper entries (rare) go to
 // a lane-private overflow area in device memory.
 #include "rt_stages.h"
-
-#include <cstdlib>
 
 namespace rtd {
 
@@ -116,7 +114,6 @@ struct PoolSlot {
     RT_DEV FrameArgs late_frame(const FrameArgs&) const { return kernarg_frame(); }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
-    RT_DEV void put_stage(uint32_t) const {}
     // bounds of a light query's search, kept in the hit fields until the search overwrites them
     RT_DEV void put_search_bounds(float t_max, float t_occl) const { L.hit_t[i] = t_max; L.hit_idx[i] = __float_as_int(t_occl); }
     RT_DEV void put_light_query(const LightQuery& q) const {
@@ -153,7 +150,8 @@ RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
 }
 
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
-// LDS and device memory) is visible to the workgroup before the entries can be claimed.
+// LDS and device memory) is visible to the workgroup before an entry can be read: state stores,
+// release fence, entry store, count.
 RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
@@ -162,9 +160,11 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     uint32_t pos = 0;
     if (lane_id() == leader) pos = atomicAdd(&L.tail[q], n);
     pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader);
-    if (want) *(volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    // Release BEFORE the entry store: entries are claimed by ring position, so another wave's count
+    // may expose this position, and its popper takes the entry the moment it stops being kEmpty.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane_id() == leader) atomicAdd(&L.hc[q], n);
+    if (want) *(volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    if (lane_id() == leader) atomicAdd(&L.hc[q], n);  // LDS operations of one wave complete in order: after the entries
 }
 
 // The same for several queues at once: every lane names its queue (0..kQueues-1, or -1 for
@@ -189,8 +189,8 @@ RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
         const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
         if (q == k) { base = pk; mk = m[k]; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // before the entry store, as in queue_push
     if (q >= 0) *(volatile lds_u16*)&L.items[q][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)] = (uint16_t)item;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane < kQueues && n_mine != 0u) atomicAdd(&L.hc[lane], n_mine);
 }
 
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }
-        if (lds_peek(&L.abort) != 0u) atomicExch(&fa.counters[30], 1u);
+        if (lds_peek(&L.abort) != 0u) *(volatile uint32_t*)kernarg_frame().abort_flag = 1u;
     }
 }
 
@@ -495,15 +495,12 @@ int pool_overflow_per_lane() { return kOverflow; }
 // Workgroups of the pooled launch: as many as are resident at once, fewer when the image
 // is small.  The path pool must hold grid * pool_slots_per_block() cold records and
 // grid * pool_threads_per_block() * pool_overflow_per_lane() stack words.
-hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, unsigned* grid) {
+hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid) {
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(accel, stats), kThreads, kStackLds);
     if (e != hipSuccess) return e;
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    if (const char* q = getenv("RT_POOL_PER_CU")) {  // tuning aid
-        int v = atoi(q);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
+    if (per_cu_cap >= 1 && per_cu_cap < per_cu) per_cu = per_cu_cap;
     // every CU takes part as long as a workgroup gets a few waves' worth of pixels
     const long long want = ((long long)fa.total_slots + kChunk - 1) / kChunk, cap = (long long)cu_count * per_cu;
     *grid = (unsigned)(want < cap ? want : cap);

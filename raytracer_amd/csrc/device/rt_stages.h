@@ -1,7 +1,6 @@
 // rt_stages.h — the per-path pieces of the shader's program between two nearest-hit
-// searches, written against an accessor of one slot of path state, so that the staged
-// pipeline (state in device memory, rt_wavefront.hip) and the pooled pipeline (hot state in
-// LDS, rt_pool.hip) run the very same arithmetic.
+// searches, written against an accessor of one slot of path state (the pooled pipeline keeps
+// the hot part of it in LDS, rt_pool.hip).
 #pragma once
 #include "rt_trace.h"
 
@@ -22,44 +21,6 @@ struct LightQuery {
     bool front_face;
     float s_d;
     int light;
-};
-
-// Accessor of slot `s` of a PathPool in device memory.
-struct GlobalSlot {
-    const PathPool& pp;
-    uint32_t s;
-    RT_DEV void get_ctl(uint32_t& seed, uint32_t& pixel, uint32_t& sample, int& bounce) const {
-        const uint4 c = pp.ctl[s];
-        seed = c.x; pixel = c.y; sample = c.z; bounce = (int)c.w;
-    }
-    RT_DEV void put_ctl(uint32_t seed, uint32_t pixel, uint32_t sample, int bounce) const { pp.ctl[s] = make_uint4(seed, pixel, sample, (uint32_t)bounce); }
-    RT_DEV V3 get_att(uint32_t& phash) const { const float4 a = pp.att[s]; phash = __float_as_uint(a.w); return xyz(a); }
-    RT_DEV void put_att(V3 a, uint32_t phash) const { pp.att[s] = f4(a, __uint_as_float(phash)); }
-    RT_DEV V3 get_ro() const { return xyz(pp.ray_o[s]); }
-    RT_DEV V3 get_rd() const { return xyz(pp.ray_d[s]); }
-    RT_DEV void put_ro(V3 v) const { pp.ray_o[s] = f4(v, 0.0f); }
-    RT_DEV void put_rd(V3 v) const { pp.ray_d[s] = f4(v, 0.0f); }
-    RT_DEV void get_hit(float& t, int& idx) const { const uint2 r = pp.hit[s]; t = __uint_as_float(r.x); idx = (int)r.y; }
-    RT_DEV V3 get_col() const { return xyz(pp.col[s]); }
-    RT_DEV void put_col(V3 v) const { pp.col[s] = f4(v, 0.0f); }
-    RT_DEV const float* camera(const FrameArgs& fa) const { return fa.view_inv; }
-    RT_DEV const FrameArgs& late_frame(const FrameArgs& fa) const { return fa; }
-    RT_DEV V3 get_pix(float& cost) const { const float4 v = pp.pix[s]; cost = v.w; return xyz(v); }
-    RT_DEV void put_pix(V3 v, float cost) const { pp.pix[s] = f4(v, cost); }
-    RT_DEV void put_stage(uint32_t st) const { pp.stage[s] = st; }
-    RT_DEV void put_search_bounds(float, float) const {}  // the staged search always finds the true nearest hit
-    RT_DEV void put_light_query(const LightQuery& q) const {
-        pp.hn[s] = f4(q.normal, q.s_d);
-        pp.vdir[s] = f4(q.vdir, __uint_as_float((uint32_t)q.light));
-        pp.hp[s] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)q.mat | (q.front_face ? 0x80000000u : 0u)));
-    }
-    RT_DEV void get_light_query(LightQuery& q) const {
-        const float4 n = pp.hn[s], v = pp.vdir[s];
-        const uint32_t mbits = __float_as_uint(pp.hp[s].w);
-        q.normal = xyz(n); q.s_d = n.w;
-        q.vdir = xyz(v); q.light = (int)__float_as_uint(v.w);
-        q.mat = (int)(mbits & 0x7fffffffu); q.front_face = (mbits >> 31) != 0u;
-    }
 };
 
 // A path result (kind 0: bounce 0, kind 1: later bounces; raytracer.comp:891-921) or a
@@ -185,7 +146,6 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
     }
     sl.put_ctl(seed, pixel, sample, bounce);
     sl.put_att(att, phash);
-    if (!to_end) sl.put_stage(next_stage);
     return to_end;
 }
 
@@ -200,7 +160,6 @@ RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uin
     sl.put_rd(rd);
     sl.put_att(v3(1.0f), phash);
     sl.put_col(v3(0.0f));
-    sl.put_stage(WF_PATH_FIRST);
 }
 
 // End of a sample (raytracer.comp:925/929, 974) and either the next sample's primary ray or
@@ -236,7 +195,6 @@ RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
         if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
         const int py = (int)(pixel / (uint32_t)ff.width);
         report_pixel_cost(ff, (int)pixel - py * ff.width, py, (uint32_t)cost);
-        sl.put_stage(WF_IDLE);
         alive = false;
     }
 }

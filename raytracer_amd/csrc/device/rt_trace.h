@@ -1,5 +1,5 @@
 // rt_trace.h — nearest-hit search building blocks shared by the single-kernel pipeline
-// (rt_kernels.hip) and the staged pipeline (rt_wavefront.hip): one primitive test with the
+// (rt_kernels.hip) and the pooled pipeline (rt_pool.hip): one primitive test with the
 // reference's tie rules, the resumable BVH step, the hit record and the rgba8 store.
 #pragma once
 #include <cstddef>

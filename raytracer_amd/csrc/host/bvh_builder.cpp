@@ -96,11 +96,7 @@ public:
     int defer_at_most = 0;
     std::vector<SubtreeTask> tasks;
 
-    static int max_leaf() {
-        static int v = [] { const char* e = getenv("RT_MAX_LEAF"); int x = e ? atoi(e) : 4; return (x >= 1 && x <= 8) ? x : 4; }();
-        return v;
-    }
-#define kMaxLeaf max_leaf()
+    int leaf_cap = 4;  // most primitives a leaf may hold (1..8)
     static const int kBins = 16;
 
     ChildRef build(int begin, int end, int depth) {
@@ -122,11 +118,11 @@ public:
         if (n <= 1) return leaf(begin, end, box);
 
         // Levels still available below this node; a subtree of n primitives needs at least
-        // ceil(log2(n / kMaxLeaf)) of them.  When SAH's freedom would risk exceeding the cap,
+        // ceil(log2(n / leaf_cap)) of them.  When SAH's freedom would risk exceeding the cap,
         // fall back to splitting the object list in half.
         int remaining = kMaxBvhDepth - depth;
         int needed = 0;
-        while (((long long)kMaxLeaf << needed) < n) ++needed;
+        while (((long long)leaf_cap << needed) < n) ++needed;
         bool force_median = needed + 2 >= remaining;
 
         int axis = -1;
@@ -173,7 +169,7 @@ public:
             if (axis >= 0) {
                 // SAH with traversal cost 1 and intersection cost 1 per primitive
                 float split_cost = 1.0f + best_cost / std::fmax(parent_area, 1e-30f);
-                if (n <= kMaxLeaf && (float)n <= split_cost) return leaf(begin, end, box);
+                if (n <= leaf_cap && (float)n <= split_cost) return leaf(begin, end, box);
                 float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
                 float scale = (float)kBins / ext;
                 auto it = std::partition(prims_.begin() + begin, prims_.begin() + end, [&](const BuildPrim& p) {
@@ -181,10 +177,10 @@ public:
                     return b <= best_bin;
                 });
                 mid = (int)(it - prims_.begin());
-            } else if (n <= kMaxLeaf) {
+            } else if (n <= leaf_cap) {
                 return leaf(begin, end, box);
             }
-        } else if (n <= kMaxLeaf) {
+        } else if (n <= leaf_cap) {
             return leaf(begin, end, box);
         }
         if (mid <= begin || mid >= end) {
@@ -346,8 +342,9 @@ bool gather_primitives(const SceneArrays& s, std::vector<PrimRecord>& out, std::
     return true;
 }
 
-bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
+bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_leaf) {
     out = HostBvh();
+    if (max_leaf < 1 || max_leaf > 8) max_leaf = 4;
     std::vector<PrimRecord> flat;
     if (!gather_primitives(s, flat, err)) return false;
     std::vector<BuildPrim> bp(flat.size());
@@ -360,6 +357,7 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
                 return fail(err, "primitive with non-finite coordinates");
     }
     Builder b(bp, out);
+    b.leaf_cap = max_leaf;
     ChildRef empty;
     empty.index = -1;
     empty.count = 0;  // box stays inverted: never entered
@@ -377,6 +375,7 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err) {
             auto work = [&]() {
                 for (size_t k = next.fetch_add(1); k < b.tasks.size(); k = next.fetch_add(1)) {
                     Builder sb(bp, sub[k].bvh);
+                    sb.leaf_cap = max_leaf;
                     sub[k].root = sb.build(b.tasks[k].begin, b.tasks[k].end, b.tasks[k].depth);
                     sub[k].sah = sb.sah_;
                     sub[k].leaf_sah = sb.leaf_sah_;

@@ -65,7 +65,8 @@ bool gather_primitives(const SceneArrays& s, std::vector<PrimRecord>& out, std::
 
 static const int kMaxBvhDepth = 30;  // traversal stacks hold kMaxBvhDepth + 2 entries
 
-bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err);
+// max_leaf: most primitives per leaf, 1..8 (anything else: 4).
+bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_leaf = 4);
 
 // Structural self-check: every node reachable exactly once, every primitive in exactly one
 // leaf, every leaf box contains its primitives, every stored child box contains the boxes

@@ -40,7 +40,15 @@ struct JVal {
         return it == obj.end() ? nullptr : &it->second;
     }
     const JVal* at(size_t i) const { return (kind == Arr && i < arr.size()) ? &arr[i] : nullptr; }
-    long long as_int(long long dflt) const { return kind == Num ? (long long)num : dflt; }
+    // Numbers come from an untrusted file: anything that is not a number of modest size reads as `dflt`
+    // (a conversion of an out-of-range double would be undefined behaviour).
+    long long as_int(long long dflt) const { return (kind == Num && num >= -9.0e15 && num <= 9.0e15) ? (long long)num : dflt; }
+    // A byte offset / length / count: a number in [0, limit], else false.
+    bool as_size(size_t limit, size_t& out) const {
+        if (kind != Num || !(num >= 0.0) || !(num <= (double)limit) || num > 9.0e15) return false;
+        out = (size_t)num;
+        return true;
+    }
 };
 
 class JParser {
@@ -155,16 +163,19 @@ bool accessor_data(const JVal& root, const std::vector<unsigned char>& bin, long
     if (!bv) return fail(err, "accessor has no bufferView");
     const JVal* bufi = bv->get("buffer");
     if (!bufi || bufi->as_int(-1) != 0) return fail(err, "only the GLB-embedded buffer 0 is supported");
-    size_t off = 0;
-    if (const JVal* o = bv->get("byteOffset")) off += (size_t)o->as_int(0);
-    if (const JVal* o = acc->get("byteOffset")) off += (size_t)o->as_int(0);
+    size_t off = 0, view_off = 0, acc_off = 0;
+    if (const JVal* o = bv->get("byteOffset"))
+        if (!o->as_size(bin.size(), view_off)) return fail(err, "bufferView offset beyond the BIN chunk");
+    if (const JVal* o = acc->get("byteOffset"))
+        if (!o->as_size(bin.size(), acc_off)) return fail(err, "accessor offset beyond the BIN chunk");
+    off = view_off + acc_off;  // each at most bin.size(): no wrap
     const JVal* cnt = acc->get("count");
     const JVal* ct = acc->get("componentType");
     if (!cnt || !ct) return fail(err, "accessor lacks count/componentType");
     if (off > bin.size()) return fail(err, "accessor offset beyond the BIN chunk");
     *data = bin.data() + off;
     *avail = bin.size() - off;
-    *count = (size_t)cnt->as_int(0);
+    if (!cnt->as_size(bin.size(), *count)) return fail(err, "accessor count is not a number the BIN chunk could hold");
     *ctype = ct->as_int(0);
     return true;
 }
@@ -237,7 +248,7 @@ bool accessor_view(const JVal& root, const std::vector<unsigned char>& bin, long
     const JVal* ct = acc->get("componentType");
     const JVal* ty = acc->get("type");
     if (!cnt || !ct || !ty || ty->kind != JVal::Str) return fail(err, "accessor lacks count/componentType/type");
-    out.count = (size_t)cnt->as_int(0);
+    if (!cnt->as_size(bin.size(), out.count)) return fail(err, "accessor count is not a number the BIN chunk could hold");
     out.ctype = ct->as_int(0);
     out.type = ty->str;
     const size_t comps = out.type == "SCALAR" ? 1 : out.type == "VEC2" ? 2 : out.type == "VEC3" ? 3 : out.type == "VEC4" ? 4 : 0;
@@ -245,21 +256,28 @@ bool accessor_view(const JVal& root, const std::vector<unsigned char>& bin, long
     if (comps == 0 || csize == 0) return fail(err, "unsupported accessor type");
     const size_t elem = comps * csize;
     size_t off = 0, view_len = bin.size();
-    if (const JVal* o = bv->get("byteOffset")) off = (size_t)o->as_int(0);
-    if (const JVal* o = bv->get("byteLength")) view_len = (size_t)o->as_int(0);
+    if (const JVal* o = bv->get("byteOffset"))
+        if (!o->as_size(bin.size(), off)) return fail(err, "bufferView beyond the BIN chunk");
+    if (const JVal* o = bv->get("byteLength"))
+        if (!o->as_size(bin.size(), view_len)) return fail(err, "bufferView beyond the BIN chunk");
     if (off > bin.size() || view_len > bin.size() - off) return fail(err, "bufferView beyond the BIN chunk");
     size_t acc_off = 0;
-    if (const JVal* o = acc->get("byteOffset")) acc_off = (size_t)o->as_int(0);
+    if (const JVal* o = acc->get("byteOffset"))
+        if (!o->as_size(bin.size(), acc_off)) return fail(err, "accessor data beyond its bufferView");
     out.stride = elem;
     if (const JVal* o = bv->get("byteStride")) {
-        const long long st = o->as_int(0);
+        size_t st = 0;
+        if (!o->as_size(bin.size(), st)) return fail(err, "byteStride is not a number the BIN chunk could hold");
         if (st != 0) {
-            if (st < (long long)elem) return fail(err, "byteStride smaller than the element");
-            out.stride = (size_t)st;
+            if (st < elem) return fail(err, "byteStride smaller than the element");
+            out.stride = st;
         }
     }
-    if (out.count != 0 && (acc_off > view_len || (out.count - 1) * out.stride + elem > view_len - acc_off))
-        return fail(err, "accessor data beyond its bufferView");
+    // (count - 1) * stride + elem <= room, compared by division so that nothing can wrap
+    if (out.count != 0) {
+        if (acc_off > view_len || elem > view_len - acc_off) return fail(err, "accessor data beyond its bufferView");
+        if (out.count - 1 > (view_len - acc_off - elem) / out.stride) return fail(err, "accessor data beyond its bufferView");
+    }
     out.data = bin.data() + off + acc_off;
     return true;
 }
@@ -414,11 +432,11 @@ bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std
     long long ctype;
     if (!accessor_data(root, bin, idx->as_int(-1), &data, &count, &ctype, &avail, err)) return false;
     if (ctype == 5123) {  // UNSIGNED_SHORT
-        if (count * 2 > avail) return fail(err, "index data beyond the BIN chunk");
+        if (count > avail / 2) return fail(err, "index data beyond the BIN chunk");
         indices.resize(count);
         for (size_t i = 0; i < count; ++i) indices[i] = (uint32_t)data[2 * i] | ((uint32_t)data[2 * i + 1] << 8);
     } else if (ctype == 5125) {  // UNSIGNED_INT
-        if (count * 4 > avail) return fail(err, "index data beyond the BIN chunk");
+        if (count > avail / 4) return fail(err, "index data beyond the BIN chunk");
         indices.resize(count);
         for (size_t i = 0; i < count; ++i) indices[i] = rd32(data + 4 * i);
     } else {
@@ -429,7 +447,7 @@ bool LoadModel(const std::string& filename, std::vector<RtVertex>& vertices, std
     const JVal* posacc = attrs ? attrs->get("POSITION") : nullptr;
     if (!posacc) return fail(err, "Primitive has no POSITION attribute");
     if (!accessor_data(root, bin, posacc->as_int(-1), &data, &count, &ctype, &avail, err)) return false;
-    if (count * 12 > avail) return fail(err, "position data beyond the BIN chunk");
+    if (count > avail / 12) return fail(err, "position data beyond the BIN chunk");
     vertices.resize(count);
     for (size_t i = 0; i < count; ++i) {
         RtVertex v;

@@ -3,12 +3,28 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 
 #include "../../../include/rt_abi.h"
 #include "bvh_builder.h"
 #include "scene_handle.h"
 
 using rt::Scene;
+
+// Nothing may throw across the C boundary: allocation failures (and whatever else a builder
+// might raise on hostile input) become status codes.
+template <typename F>
+static int guarded(F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return RT_ERR_TOO_LARGE;
+    } catch (const std::length_error&) {
+        return RT_ERR_TOO_LARGE;
+    } catch (...) {
+        return RT_ERR_IO;
+    }
+}
 
 extern "C" {
 
@@ -29,11 +45,12 @@ void rt_default_params(RtParams* out) {
 int rt_scene_create(int preset, const char* assets_dir, RtScene** out) {
     if (!out || preset < RT_SCENE_EMPTY || preset > RT_SCENE_PRESET1_TEAPOT) return RT_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    RtScene* s = new (std::nothrow) RtScene(preset, assets_dir ? assets_dir : "assets/");
-    if (!s) return RT_ERR_TOO_LARGE;
-    *out = s;
-    // A model that failed to load leaves an empty mesh behind, as in the reference; tell the caller.
-    return s->scene.last_error.empty() ? RT_OK : RT_ERR_IO;
+    return guarded([&]() -> int {
+        RtScene* s = new RtScene(preset, assets_dir ? assets_dir : "assets/");
+        *out = s;
+        // A model that failed to load leaves an empty mesh behind, as in the reference; tell the caller.
+        return s->scene.last_error.empty() ? RT_OK : RT_ERR_IO;
+    });
 }
 
 int rt_scene_destroy(RtScene* s) {
@@ -45,7 +62,7 @@ static bool mat_ok(const Scene& sc, int32_t mat) { return mat >= 0 && mat < (int
 
 int rt_scene_add_material(RtScene* s, const RtMaterial* m) {
     if (!s || !m) return RT_ERR_INVALID_ARGUMENT;
-    return s->scene.addMaterial(*m);
+    return guarded([&]() -> int { return s->scene.addMaterial(*m); });
 }
 
 int rt_scene_add_sphere(RtScene* s, const float pos[3], float r, int32_t mat) {
@@ -55,8 +72,7 @@ int rt_scene_add_sphere(RtScene* s, const float pos[3], float r, int32_t mat) {
     memcpy(sp.pos, pos, 12);
     sp.r = r;
     sp.mat = mat;
-    s->scene.addSphere(sp);
-    return RT_OK;
+    return guarded([&]() -> int { s->scene.addSphere(sp); return RT_OK; });
 }
 
 int rt_scene_add_triangle(RtScene* s, const float v0[3], const float v1[3], const float v2[3], int32_t mat) {
@@ -67,8 +83,7 @@ int rt_scene_add_triangle(RtScene* s, const float v0[3], const float v1[3], cons
     memcpy(t.v1, v1, 12);
     memcpy(t.v2, v2, 12);
     t.mat = mat;
-    s->scene.addTriangle(t);
-    return RT_OK;
+    return guarded([&]() -> int { s->scene.addTriangle(t); return RT_OK; });
 }
 
 int rt_scene_add_quad(RtScene* s, const float v0[3], const float v1[3], const float v2[3], const float v3[3], int32_t mat) {
@@ -79,8 +94,7 @@ int rt_scene_add_quad(RtScene* s, const float v0[3], const float v1[3], const fl
     q.v2 = rtm::v3(v2[0], v2[1], v2[2]);
     q.v3 = rtm::v3(v3[0], v3[1], v3[2]);
     q.mat = mat;
-    s->scene.addQuad(q);
-    return RT_OK;
+    return guarded([&]() -> int { s->scene.addQuad(q); return RT_OK; });
 }
 
 int rt_scene_add_light(RtScene* s, const float pos_angle_aux[4], const float color_str[4], int32_t type) {
@@ -90,23 +104,26 @@ int rt_scene_add_light(RtScene* s, const float pos_angle_aux[4], const float col
     memcpy(l.pos_angle_aux, pos_angle_aux, 16);
     memcpy(l.color_str, color_str, 16);
     l.type = type;
-    s->scene.addLight(l);
-    return RT_OK;
+    return guarded([&]() -> int { s->scene.addLight(l); return RT_OK; });
 }
 
 int rt_scene_add_model(RtScene* s, const char* file_name, const float pos[3], float pitch, float yaw, float roll,
                        float scale, int32_t material) {
     if (!s || !file_name || !pos || !mat_ok(s->scene, material)) return RT_ERR_INVALID_ARGUMENT;
-    rt::Model m{file_name, rtm::v3(pos[0], pos[1], pos[2]), pitch, yaw, roll, scale, material};
-    return s->scene.addModel(m) ? RT_OK : RT_ERR_IO;
+    return guarded([&]() -> int {
+        rt::Model m{file_name, rtm::v3(pos[0], pos[1], pos[2]), pitch, yaw, roll, scale, material};
+        return s->scene.addModel(m) ? RT_OK : RT_ERR_IO;
+    });
 }
 
 int rt_scene_add_model_ex(RtScene* s, const char* file_name, const float pos[3], float pitch, float yaw, float roll,
                           float scale, int32_t material, uint32_t flags) {
     if (!s || !file_name || !pos || !mat_ok(s->scene, material)) return RT_ERR_INVALID_ARGUMENT;
     if (flags & ~(uint32_t)(RT_MODEL_FULL_GLTF | RT_MODEL_REBASE_INDICES)) return RT_ERR_INVALID_ARGUMENT;
-    rt::Model m{file_name, rtm::v3(pos[0], pos[1], pos[2]), pitch, yaw, roll, scale, material};
-    return s->scene.addModelEx(m, flags) ? RT_OK : RT_ERR_IO;
+    return guarded([&]() -> int {
+        rt::Model m{file_name, rtm::v3(pos[0], pos[1], pos[2]), pitch, yaw, roll, scale, material};
+        return s->scene.addModelEx(m, flags) ? RT_OK : RT_ERR_IO;
+    });
 }
 
 int rt_scene_view(const RtScene* s, RtSceneView* out) {

@@ -15,72 +15,37 @@
 #include "device/rt_kernels.h"
 #include "host/bvh_builder.h"
 #include "host/scene_handle.h"
-
-struct RtContext {
-    int device = 0;
-    int cu_count = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    bool timed = false;
-    int32_t last_pipeline = 0;
-
-    // scene
-    bool has_scene = false;
-    void* d_prims_bvh = nullptr;
-    void* d_prims_flat = nullptr;
-    void* d_nodes = nullptr;
-    void* d_materials = nullptr;
-    void* d_lights = nullptr;
-    void* d_triangles = nullptr;
-    int32_t n_prims = 0, n_spheres = 0, n_triangles = 0, n_meshes = 0, n_lights = 0, n_materials = 0;
-    int32_t bvh_nodes = 0, bvh_depth = 0;
-
-    // framebuffer
-    int32_t width = 0, height = 0;
-    bool owns_fb = false;
-    void* d_accum = nullptr;
-    void* d_counts = nullptr;
-    void* d_bgra = nullptr;
-    int32_t* d_primary_ids = nullptr;
-    uint32_t* d_path_hash = nullptr;
-    uint32_t* d_counters = nullptr;  // 48 x u32, see FrameArgs::counters
-    // tile order fed back from frame to frame (see FrameArgs::tile_order)
-    uint32_t* d_tile_order = nullptr;
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t tile_capacity = 0;
-    bool order_ready = false;           // d_tile_order holds the order made from the last frame
-    int32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // width, height, strip_rows, strip_count, strip_index, tiles it was made for
-    // choice between the pooled and the single kernel by measurement (see rt_render_frame)
-    int32_t scene_generation = 0;
-    int32_t tune_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int tune_stage = 0;       // frames of this configuration so far (saturating): 0-2 pooled, 3-4 single, then the choice
-    float tune_pooled_ms = 0.0f;
-    int tune_choice = RT_PIPELINE_POOLED;
-
-    // path state of the staged pipeline (allocated on first use, grown when needed)
-    void* d_pool = nullptr;
-    size_t pool_bytes = 0;
-    uint32_t* d_active = nullptr;
-    size_t active_len = 0;
-
-    std::string err;
-};
+#include "rt_context.h"
 
 namespace {
-
 std::string g_create_error;
+}
 
+namespace rtapi {
 int fail(RtContext* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_error = msg;
     return code;
 }
+int check_abandoned(RtContext* c) {
+    if (c->h_abort && *(volatile uint32_t*)c->h_abort != 0u) {
+        *(volatile uint32_t*)c->h_abort = 0u;
+        return fail(c, RT_ERR_HIP, "the pooled pipeline gave up waiting for work inside a workgroup; a frame since the last synchronisation is incomplete");
+    }
+    return RT_OK;
+}
+}  // namespace rtapi
+using rtapi::fail;
 
-#define RT_HIP(ctx, call)                                                                                   \
-    do {                                                                                                    \
-        hipError_t e_ = (call);                                                                             \
-        if (e_ != hipSuccess)                                                                               \
-            return fail((ctx), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
-    } while (0)
+namespace {
+
+// Device memory a frame needs beyond the scene and the framebuffer.
+struct FrameScratch {
+    uint32_t* counters = nullptr;    // 48 words (FrameArgs::counters)
+    uint32_t* tile_cost = nullptr;   // per 8x8 tile, this frame's cost
+    uint32_t* tile_order = nullptr;  // the order to hand the tiles out in (null: image order)
+    void* pool = nullptr;            // cold slot records + stack overflow of the pooled kernel
+    size_t pool_bytes = 0;
+};
 
 void free_scene(RtContext* c) {
     void** ptrs[] = {&c->d_prims_bvh, &c->d_prims_flat, &c->d_nodes, &c->d_materials, &c->d_lights, &c->d_triangles};
@@ -117,14 +82,11 @@ int upload_array(RtContext* c, void** dst, const void* src, size_t bytes, size_t
 
 void free_pool(RtContext* c) {
     if (c->d_pool) (void)hipFree(c->d_pool);
-    if (c->d_active) (void)hipFree(c->d_active);
     c->d_pool = nullptr;
-    c->d_active = nullptr;
     c->pool_bytes = 0;
-    c->active_len = 0;
 }
 
-// Device memory of the staged / pooled pipelines: one allocation, grown when needed.
+// Device memory of the pooled pipeline: one allocation, grown when needed.
 int ensure_pool_bytes(RtContext* c, size_t bytes) {
     if (bytes > c->pool_bytes) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -138,52 +100,16 @@ int ensure_pool_bytes(RtContext* c, size_t bytes) {
     return RT_OK;
 }
 
-// Staged pipeline: 156 B of path state per slot (stage word, ctl, hit, nine float4 arrays),
-// carved out of the allocation 16-byte arrays first, plus the per-iteration live counters.
-int ensure_staged_pool(RtContext* c, size_t n_slots, size_t iterations, rtd::PathPool& pp) {
-    const size_t cap = (n_slots + 255) / 256 * 256;
-    int rc = ensure_pool_bytes(c, cap * (4 + 16 + 8 + 9 * 16));
-    if (rc != RT_OK) return rc;
-    if (iterations + 2 > c->active_len) {
-        RT_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->d_active) (void)hipFree(c->d_active);
-        c->d_active = nullptr;
-        c->active_len = 0;
-        size_t len = iterations + 2 + 256;
-        RT_HIP(c, hipMalloc((void**)&c->d_active, len * 4));
-        c->active_len = len;
-    }
-    char* p = (char*)c->d_pool;
-    auto take = [&](size_t bytes_per_slot) { char* r = p; p += cap * bytes_per_slot; return (void*)r; };
-    pp.ctl = (uint4*)take(16);
-    pp.ray_o = (float4*)take(16);
-    pp.ray_d = (float4*)take(16);
-    pp.att = (float4*)take(16);
-    pp.col = (float4*)take(16);
-    pp.pix = (float4*)take(16);
-    pp.hp = (float4*)take(16);
-    pp.hn = (float4*)take(16);
-    pp.vdir = (float4*)take(16);
-    pp.hit = (uint2*)take(8);
-    pp.stage = (uint32_t*)take(4);
-    pp.active = c->d_active;
-    pp.n_slots = (uint32_t)n_slots;
-    pp.cold = nullptr;
-    pp.stack_overflow = nullptr;
-    return RT_OK;
-}
-
 // Pooled pipeline: per workgroup 64 B of cold state per slot and a stack overflow area per lane.
-int ensure_pooled_pool(RtContext* c, unsigned grid, rtd::PathPool& pp) {
-    memset(&pp, 0, sizeof pp);
+size_t pooled_pool_bytes(unsigned grid) {
+    return (size_t)grid * ((size_t)rtd::pool_slots_per_block() * 64 +
+                           (size_t)rtd::pool_threads_per_block() * (size_t)rtd::pool_overflow_per_lane() * 4);
+}
+void carve_pooled_pool(void* base, unsigned grid, rtd::PathPool& pp) {
     const size_t cold = (size_t)grid * (size_t)rtd::pool_slots_per_block() * 64;
-    const size_t ovf = (size_t)grid * (size_t)rtd::pool_threads_per_block() * (size_t)rtd::pool_overflow_per_lane() * 4;
-    int rc = ensure_pool_bytes(c, cold + ovf);
-    if (rc != RT_OK) return rc;
-    pp.cold = (float4*)c->d_pool;
-    pp.stack_overflow = (uint32_t*)((char*)c->d_pool + cold);
+    pp.cold = (float4*)base;
+    pp.stack_overflow = (uint32_t*)((char*)base + cold);
     pp.n_slots = grid * (unsigned)rtd::pool_slots_per_block();
-    return RT_OK;
 }
 
 int alloc_debug_buffers(RtContext* c) {
@@ -224,12 +150,22 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev_begin);
     hipError_t e3 = hipEventCreate(&c->ev_end);
+    for (int k = 0; k < 4 && e3 == hipSuccess; ++k) e3 = hipEventCreate(&c->ev_trial[k >> 1][k & 1]);
     hipError_t e4 = hipMalloc((void**)&c->d_counters, 192);
     if (e4 == hipSuccess) e4 = hipMemset(c->d_counters, 0, 192);
+    if (e4 == hipSuccess) e4 = hipHostMalloc((void**)&c->h_abort, 64, hipHostMallocMapped);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
     }
+    *c->h_abort = 0u;
+    // tuning aids: the environment may override an option's default, read once here
+    struct { const char* name; int option; } env[] = {
+        {"RT_EXIT_QUOTA_PCT", RT_OPT_EXIT_QUOTA_PCT}, {"RT_REFILL_MIN", RT_OPT_REFILL_MIN}, {"RT_POOL_BURST", RT_OPT_POOL_BURST},
+        {"RT_POOL_JOB_MIN", RT_OPT_POOL_JOB_MIN}, {"RT_TILE_CLASSES", RT_OPT_TILE_CLASSES}, {"RT_POOL_PER_CU", RT_OPT_POOL_PER_CU},
+        {"RT_MAX_LEAF", RT_OPT_BVH_MAX_LEAF}};
+    for (const auto& e : env)
+        if (const char* v = getenv(e.name)) (void)rt_set_option(c, e.option, atoi(v));  // out-of-range values are ignored
     *out_ctx = c;
     return RT_OK;
 }
@@ -242,6 +178,9 @@ int rt_destroy(RtContext* c) {
     free_framebuffer(c);
     free_pool(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_abort) (void)hipHostFree(c->h_abort);
+    for (int k = 0; k < 4; ++k)
+        if (c->ev_trial[k >> 1][k & 1]) (void)hipEventDestroy(c->ev_trial[k >> 1][k & 1]);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -287,7 +226,7 @@ int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, co
     if (!rt::gather_primitives(a, flat, &err)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
     if (flat.size() >= (size_t)(1u << 28)) return fail(c, RT_ERR_TOO_LARGE, "more than 2^28 primitives");
     rt::HostBvh bvh;
-    if (!rt::build_bvh(a, bvh, &err)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
+    if (!rt::build_bvh(a, bvh, &err, c->opt.bvh_max_leaf)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
     if (bvh.depth > rt::kMaxBvhDepth || bvh.max_leaf > 8) return fail(c, RT_ERR_TOO_LARGE, "BVH exceeds traversal limits");
 
     RT_HIP(c, hipSetDevice(c->device));
@@ -368,17 +307,18 @@ int rt_bind_framebuffer(RtContext* c, int32_t width, int32_t height, void* d_acc
     return RT_OK;
 }
 
-int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params) {
-    if (!c) return RT_ERR_INVALID_ARGUMENT;
+// Everything rt_render_frame checks and derives before it touches the device: the kernels' argument
+// blocks for this frame (output pointers, scratch and tile order still unset).
+static int prepare_frame(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int32_t width,
+                         int32_t height, RtParams& p, rtd::DeviceScene& sc, rtd::FrameArgs& fa) {
     if (!camera || !pc) return fail(c, RT_ERR_INVALID_ARGUMENT, "camera / push constants are null");
     if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
-    if (!c->d_accum) return fail(c, RT_ERR_NO_FRAMEBUFFER, "rt_resize / rt_bind_framebuffer has not been called");
-    RtParams p;
     if (params) p = *params; else rt_default_params(&p);
     if (p.spp <= 0 || p.max_bounces < 0 || p.spp > 65536 || p.max_bounces > 65536)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "spp / max_bounces out of range");
     if (p.accel != RT_ACCEL_FLAT && p.accel != RT_ACCEL_BVH) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown accel");
     if (p.skybox < RT_SKY_GREY || p.skybox > RT_SKY_BLACK) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown skybox");
+    if (p.flags & RT_FLAG_RESERVED_16) return fail(c, RT_ERR_UNSUPPORTED, "flag 16 selected a pipeline that no longer exists");
     if (p.strip_rows > 0 && (p.strip_count < 1 || p.strip_index < 0 || p.strip_index >= p.strip_count))
         return fail(c, RT_ERR_INVALID_ARGUMENT, "bad strip partition");
     // The acceleration structure was built for the uploaded element counts; the loop bounds
@@ -388,7 +328,6 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     if (pc->total_lights < 0 || pc->total_lights > c->n_lights)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "push-constant light count exceeds the uploaded lights");
 
-    rtd::DeviceScene sc;
     sc.prims_bvh = (const float4*)c->d_prims_bvh;
     sc.prims_flat = (const float4*)c->d_prims_flat;
     sc.nodes = (const float4*)c->d_nodes;
@@ -399,7 +338,6 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     sc.n_spheres = c->n_spheres;
     sc.n_triangles = c->n_triangles;
 
-    rtd::FrameArgs fa;
     memcpy(fa.view_inv, camera->viewInv, 64);
     memcpy(fa.cam_pos, camera->position, 12);
     fa.tan_half_fov = camera->tanHalfFOV;
@@ -409,52 +347,91 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     fa.total_lights = pc->total_lights;
     fa.lights_strength_sum = pc->lights_strength_sum;
     fa.reset = pc->reset_frame_accumulation ? 1u : 0u;
-    fa.width = c->width;
-    fa.height = c->height;
+    fa.width = width;
+    fa.height = height;
     fa.spp = p.spp;
     fa.max_bounces = p.max_bounces;
     fa.strip_rows = p.strip_rows > 0 ? p.strip_rows : 0;
     fa.strip_count = p.strip_rows > 0 ? p.strip_count : 1;
     fa.strip_index = p.strip_rows > 0 ? p.strip_index : 0;
-    int owned = c->height;
+    int owned = height;
     if (p.strip_rows > 0) {
         owned = 0;
-        int n_strips = (c->height + p.strip_rows - 1) / p.strip_rows;
+        int n_strips = (height + p.strip_rows - 1) / p.strip_rows;
         for (int s = p.strip_index; s < n_strips; s += p.strip_count) {
-            int rows = c->height - s * p.strip_rows;
+            int rows = height - s * p.strip_rows;
             owned += rows < p.strip_rows ? rows : p.strip_rows;
         }
     }
     fa.owned_rows = owned;
     const int block_px = 1 << rtd::kBlockPixLog2;
-    fa.tiles_x = (c->width + block_px - 1) / block_px;
+    fa.tiles_x = (width + block_px - 1) / block_px;
     fa.total_slots = ((uint32_t)fa.tiles_x * (uint32_t)((owned + block_px - 1) / block_px)) << rtd::kBlockSlotsLog2;
     fa.flags = p.flags;
-    fa.exit_quota_pct = 75;
-    if (const char* q = getenv("RT_EXIT_QUOTA_PCT")) {  // tuning aid
-        int v = atoi(q);
-        if (v >= 1 && v <= 100) fa.exit_quota_pct = v;
-    }
+    fa.exit_quota_pct = c->opt.exit_quota_pct;
     fa.accel = p.accel;
     fa.skybox = p.skybox;
-    fa.stack_depth = c->bvh_depth + 2 < 4 ? 4 : (c->bvh_depth + 2 > rtd::kStackDepth ? rtd::kStackDepth : c->bvh_depth + 2);
-    fa.accum = (float4*)c->d_accum;
-    fa.counts = (int32_t*)c->d_counts;
-    fa.bgra = (uint32_t*)c->d_bgra;
+    fa.accum = nullptr;
+    fa.counts = nullptr;
+    fa.bgra = nullptr;
     fa.primary_ids = nullptr;
     fa.path_hash = nullptr;
     fa.counters = c->d_counters;
+    fa.abort_flag = c->h_abort;
     fa.tile_order = nullptr;
     fa.tile_cost = nullptr;
+    return RT_OK;
+}
+
+// 16-bit sample / bounce counters in LDS; light and material index share a word of the slot record
+static bool pooled_fits(const RtContext* c, const RtParams& p) {
+    return p.spp <= 65535 && p.max_bounces <= 65534 && c->n_lights <= 32768 && c->n_materials <= 65536;
+}
+
+// Clears the frame's counters and launches its kernel between the context's two timing events.
+// `pool` must hold pooled_pool_bytes(grid) bytes when the pooled kernel runs.
+static int launch_frame(RtContext* c, const rtd::DeviceScene& sc, const rtd::FrameArgs& fa, const RtParams& p, int pipeline, unsigned grid,
+                        void* pool) {
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 152, c->stream));
+    RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
+    if (fa.total_slots > 0) {
+        const bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
+        if (pipeline == RT_PIPELINE_POOLED) {
+            rtd::PathPool pp;
+            carve_pooled_pool(pool, grid, pp);
+            RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, c->opt.refill_min, c->opt.pool_burst, c->opt.pool_job_min, c->stream));
+        } else {
+            RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, c->cu_count, c->stream));
+        }
+    }
+    RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
+    c->timed = true;
+    c->last_pipeline = pipeline;
+    return RT_OK;
+}
+
+int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->d_accum && c->has_scene && camera && pc) return fail(c, RT_ERR_NO_FRAMEBUFFER, "rt_resize / rt_bind_framebuffer has not been called");
+    RtParams p;
+    rtd::DeviceScene sc;
+    rtd::FrameArgs fa;
+    int rc = prepare_frame(c, camera, pc, params, c->width, c->height, p, sc, fa);
+    if (rc != RT_OK) return rc;
+    fa.accum = (float4*)c->d_accum;
+    fa.counts = (int32_t*)c->d_counts;
+    fa.bgra = (uint32_t*)c->d_bgra;
 
     RT_HIP(c, hipSetDevice(c->device));
     // Tile order: each frame records what its tiles cost, and the next frame of the same size
     // and partition hands the dear tiles out first (same pixels, same results, shorter tail).
     const uint32_t n_tiles = fa.total_slots >> rtd::kBlockSlotsLog2;  // blocks, the unit of the order
-    const bool feedback = !(p.flags & RT_FLAG_FIXED_TILE_ORDER) && n_tiles > 0;
+    const bool feedback = !(p.flags & RT_FLAG_FIXED_TILE_ORDER) && n_tiles > 0 && n_tiles <= rtd::tile_order_max_tiles();
     if (feedback) {
         const int32_t key[6] = {fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index, (int32_t)n_tiles};
         if (n_tiles > c->tile_capacity) {
+            RT_HIP(c, hipStreamSynchronize(c->stream));
             if (c->d_tile_order) (void)hipFree(c->d_tile_order);
             if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
             c->d_tile_order = c->d_tile_cost = nullptr;
@@ -473,105 +450,80 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         if (c->order_ready) fa.tile_order = c->d_tile_order;
     }
     if (p.flags & (RT_FLAG_PRIMARY_IDS | RT_FLAG_PATH_HASH)) {
-        int rc = alloc_debug_buffers(c);
+        rc = alloc_debug_buffers(c);
         if (rc != RT_OK) return rc;
         if (p.flags & RT_FLAG_PRIMARY_IDS) fa.primary_ids = c->d_primary_ids;
         if (p.flags & RT_FLAG_PATH_HASH) fa.path_hash = c->d_path_hash;
     }
-    // kernel time of the previous frame while its events are still intact: needed when that frame
-    // was one of the timed trials of the pipeline choice below
-    float prev_ms = -1.0f;
-    if (c->timed && (c->tune_stage == 3 || c->tune_stage == 5)) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(c->ev_end) == hipSuccess && hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess)
-            prev_ms = ms;
-    }
-    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 32, c->stream));
-    RT_HIP(c, hipMemsetAsync(c->d_counters + 10, 0, 152, c->stream));
-    RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
-    if (fa.total_slots > 0) {
-        bool stats = (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0;
-        int refill_min = 16;
-        if (const char* q = getenv("RT_REFILL_MIN")) {  // tuning aid
-            int v = atoi(q);
-            if (v >= 1 && v <= 64) refill_min = v;
+
+    // which schedule of the per-path program runs this frame (see rt_abi.h)
+    int pipeline = RT_PIPELINE_SINGLE;
+    int trial = -1;  // 0 / 1: this frame is the timed pooled / single trial of its configuration
+    if (p.flags & RT_FLAG_POOLED) {
+        if (!pooled_fits(c, p))
+            return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline holds at most 65535 samples, 65534 bounces, 32768 lights and 65536 materials");
+        pipeline = RT_PIPELINE_POOLED;
+    } else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits(c, p) && fa.total_slots >= 16384u) {
+        // Neither kernel wins everywhere (the pooled one on most frames, the single one on big scenes
+        // with few samples): of a configuration's first frames, 0-2 run pooled (the third one timed,
+        // once the tile order and the clocks have settled) and 3-4 single (the second one timed); later
+        // frames run the faster of the two as soon as both timings have arrived - the events are only
+        // queried, never waited for - and pooled until then.  Frames of a few thousand pixels are not worth it.
+        const int32_t key[9] = {c->scene_generation, fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index,
+                                p.spp, p.max_bounces, feedback ? 1 : 0};
+        if (memcmp(key, c->tune_key, sizeof key) != 0) {
+            memcpy(c->tune_key, key, sizeof key);
+            c->tune_stage = 0;
+            c->tune_decided = false;
         }
-        // which schedule of the per-path program runs this frame (see rt_abi.h)
-        // 16-bit sample / bounce counters in LDS; light and material index share a word of the slot record
-        const bool pooled_fits = p.spp <= 65535 && p.max_bounces <= 65534 && c->n_lights <= 32768 && c->n_materials <= 65536;
-        unsigned grid = 0;
-        int pipeline = RT_PIPELINE_SINGLE;
-        if (p.flags & RT_FLAG_POOLED) pipeline = RT_PIPELINE_POOLED;
-        else if (p.flags & RT_FLAG_WAVEFRONT) pipeline = RT_PIPELINE_STAGED;
-        else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits) {
-            if (fa.total_slots >= 16384u) {
-                // Neither kernel wins everywhere (the pooled one on most frames, the single one on big
-                // scenes with few samples): the first frames of a configuration time one after the
-                // other, the rest use the faster.  Frames of a few thousand pixels are not worth it.
-                const int32_t key[9] = {c->scene_generation, fa.width, fa.height, fa.strip_rows, fa.strip_count, fa.strip_index,
-                                        p.spp, p.max_bounces, feedback ? 1 : 0};
-                if (memcmp(key, c->tune_key, sizeof key) != 0) {
-                    memcpy(c->tune_key, key, sizeof key);
-                    c->tune_stage = 0;
+        if (c->tune_stage <= 2) pipeline = RT_PIPELINE_POOLED;
+        else if (c->tune_stage <= 4) pipeline = RT_PIPELINE_SINGLE;
+        else {
+            if (!c->tune_decided && hipEventQuery(c->ev_trial[0][1]) == hipSuccess && hipEventQuery(c->ev_trial[1][1]) == hipSuccess) {
+                float pooled_ms = 0.0f, single_ms = 0.0f;
+                if (hipEventElapsedTime(&pooled_ms, c->ev_trial[0][0], c->ev_trial[0][1]) == hipSuccess &&
+                    hipEventElapsedTime(&single_ms, c->ev_trial[1][0], c->ev_trial[1][1]) == hipSuccess) {
+                    c->tune_choice = (single_ms < pooled_ms) ? RT_PIPELINE_SINGLE : RT_PIPELINE_POOLED;
+                    c->tune_decided = true;
                 }
-                // frames 0-2 pooled (the third one timed, once the tile order and the clocks have settled),
-                // frames 3-4 single (the second one timed), from frame 5 on the faster of the two
-                if (prev_ms >= 0.0f && c->tune_stage == 3) c->tune_pooled_ms = prev_ms;
-                if (prev_ms >= 0.0f && c->tune_stage == 5)
-                    c->tune_choice = (prev_ms < c->tune_pooled_ms) ? RT_PIPELINE_SINGLE : RT_PIPELINE_POOLED;
-                if (c->tune_stage <= 2) pipeline = RT_PIPELINE_POOLED;
-                else if (c->tune_stage <= 4) pipeline = RT_PIPELINE_SINGLE;
-                else pipeline = c->tune_choice;
-                if (c->tune_stage < 6) c->tune_stage++;
             }
+            pipeline = c->tune_decided ? c->tune_choice : RT_PIPELINE_POOLED;
         }
-        c->last_pipeline = pipeline;
-        if (pipeline == RT_PIPELINE_POOLED) {
-            RT_HIP(c, rtd::pool_grid(fa, p.accel, stats, c->cu_count, &grid));
-            if (!pooled_fits)
-                return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline holds at most 65535 samples, 65534 bounces, 32768 lights and 65536 materials");
-            rtd::PathPool pp;
-            int rc = ensure_pooled_pool(c, grid, pp);
-            if (rc != RT_OK) return rc;
-            int burst = 16;
-            if (const char* q = getenv("RT_POOL_BURST")) {  // tuning aid
-                int v = atoi(q);
-                if (v >= 1 && v <= 1024) burst = v;
-            }
-            int job_min = 64;
-            if (const char* q = getenv("RT_POOL_JOB_MIN")) {  // tuning aid
-                int v = atoi(q);
-                if (v >= 1 && v <= 64) job_min = v;
-            }
-            RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
-            RT_HIP(c, rtd::launch_pool(sc, fa, pp, p.accel, stats, grid, refill_min, burst, job_min, c->stream));
-        } else if (pipeline == RT_PIPELINE_STAGED) {
-            // every live path advances by one ray per iteration; a sample needs at most
-            // max_bounces + 1 path rays and one light query
-            long long iterations = (long long)p.spp * ((long long)p.max_bounces + 2);
-            if (iterations > (1ll << 20)) return fail(c, RT_ERR_TOO_LARGE, "spp x (max_bounces + 2) exceeds 2^20 launches pairs");
-            rtd::PathPool pp;
-            int rc = ensure_staged_pool(c, fa.total_slots, (size_t)iterations, pp);
-            if (rc != RT_OK) return rc;
-            RT_HIP(c, hipMemsetAsync(c->d_active, 0, ((size_t)iterations + 2) * 4, c->stream));
-            RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
-            RT_HIP(c, rtd::launch_wavefront(sc, fa, pp, p.accel, stats, (int)iterations, refill_min, c->cu_count, c->stream));
-        } else {
-            RT_HIP(c, rtd::launch_render(sc, fa, p.accel, stats, c->cu_count, c->stream));
-        }
+        if (c->tune_stage == 2) trial = 0;
+        if (c->tune_stage == 4) trial = 1;
+        if (c->tune_stage < 5) c->tune_stage++;
     }
-    RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
-    c->timed = true;
+    unsigned grid = 0;
+    if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
+        RT_HIP(c, rtd::pool_grid(fa, p.accel, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, c->cu_count, c->opt.pool_per_cu, &grid));
+        rc = ensure_pool_bytes(c, pooled_pool_bytes(grid));
+        if (rc != RT_OK) return rc;
+    }
+    if (trial >= 0) RT_HIP(c, hipEventRecord(c->ev_trial[trial][0], c->stream));
+    rc = launch_frame(c, sc, fa, p, pipeline, grid, c->d_pool);
+    if (rc != RT_OK) return rc;
+    if (trial >= 0) RT_HIP(c, hipEventRecord(c->ev_trial[trial][1], c->stream));
     if (feedback && fa.total_slots > 0) {
-        int classes = 16;
-        if (const char* q = getenv("RT_TILE_CLASSES")) {  // tuning aid
-            int v = atoi(q);
-            if (v >= 1 && v <= 64) classes = v;
-        }
-        RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, classes, c->stream));
+        RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, c->opt.tile_classes, nullptr, nullptr, c->stream));
         c->order_ready = true;
     }
     return RT_OK;
+}
+
+int rt_set_option(RtContext* c, int option, int value) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    struct { int option; int* field; int lo, hi; } table[] = {
+        {RT_OPT_EXIT_QUOTA_PCT, &c->opt.exit_quota_pct, 1, 100}, {RT_OPT_REFILL_MIN, &c->opt.refill_min, 1, 64},
+        {RT_OPT_POOL_BURST, &c->opt.pool_burst, 1, 1024},        {RT_OPT_POOL_JOB_MIN, &c->opt.pool_job_min, 1, 64},
+        {RT_OPT_TILE_CLASSES, &c->opt.tile_classes, 1, 64},      {RT_OPT_POOL_PER_CU, &c->opt.pool_per_cu, 0, 8},
+        {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8}};
+    for (const auto& t : table) {
+        if (t.option != option) continue;
+        if (value < t.lo || value > t.hi) return fail(c, RT_ERR_INVALID_ARGUMENT, "option value out of range");
+        *t.field = value;
+        return RT_OK;
+    }
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown option");
 }
 
 int rt_resolve(RtContext* c) {
@@ -589,7 +541,7 @@ int rt_read_output_bgra8(RtContext* c, void* dst) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(dst, c->d_bgra, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
+    return rtapi::check_abandoned(c);
 }
 
 int rt_read_accum(RtContext* c, float* accum, int32_t* counts) {
@@ -600,7 +552,7 @@ int rt_read_accum(RtContext* c, float* accum, int32_t* counts) {
     size_t n = (size_t)c->width * c->height;
     if (accum) RT_HIP(c, hipMemcpy(accum, c->d_accum, n * 16, hipMemcpyDeviceToHost));
     if (counts) RT_HIP(c, hipMemcpy(counts, c->d_counts, n * 4, hipMemcpyDeviceToHost));
-    return RT_OK;
+    return rtapi::check_abandoned(c);
 }
 
 int rt_read_debug(RtContext* c, int32_t* primary_ids, uint32_t* path_hash) {
@@ -638,8 +590,7 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     out->bvh_depth = c->bvh_depth;
     out->total_prims = c->n_prims;
     out->pipeline = c->last_pipeline;
-    if (h[30] != 0u) return fail(c, RT_ERR_HIP, "the pooled pipeline gave up waiting for work inside a workgroup; the last frame is incomplete");
-    return RT_OK;
+    return rtapi::check_abandoned(c);
 }
 
 int rt_get_device_buffers(RtContext* c, void** d_accum, void** d_counts, void** d_bgra8) {
@@ -678,7 +629,7 @@ int rt_sync(RtContext* c) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    return RT_OK;
+    return rtapi::check_abandoned(c);
 }
 
 const char* rt_last_error(RtContext* c) { return c ? c->err.c_str() : g_create_error.c_str(); }

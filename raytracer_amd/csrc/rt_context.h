@@ -1,0 +1,87 @@
+// rt_context.h — the RtContext behind the C ABI of include/rt_abi.h, shared by rt_api.hip (one
+// device) and rt_group.hip (several devices combined over RCCL).  Internal: not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/rt_abi.h"
+
+// Tuning knobs (rt_set_option; defaults may be overridden once, at rt_create, by the environment
+// variables named in rt_api.hip).
+struct RtOptions {
+    int exit_quota_pct = 75;  // single kernel: the search loop returns once this share of the busy lanes has a result
+    int refill_min = 16;      // pooled kernel: idle lanes of a searching wave before it fetches new rays
+    int pool_burst = 16;      // pooled kernel: search steps between two looks at the queues
+    int pool_job_min = 64;    // pooled kernel: queue entries that make a shading job
+    int tile_classes = 16;    // cost classes of the frame-to-frame tile order
+    int pool_per_cu = 0;      // pooled kernel: cap on workgroups per CU (0: what fits)
+    int bvh_max_leaf = 4;     // builder: most primitives per leaf (takes effect at the next rt_upload_scene)
+};
+
+struct RtContext {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+    int32_t last_pipeline = 0;
+    RtOptions opt;
+
+    // scene
+    bool has_scene = false;
+    void* d_prims_bvh = nullptr;
+    void* d_prims_flat = nullptr;
+    void* d_nodes = nullptr;
+    void* d_materials = nullptr;
+    void* d_lights = nullptr;
+    void* d_triangles = nullptr;
+    int32_t n_prims = 0, n_spheres = 0, n_triangles = 0, n_meshes = 0, n_lights = 0, n_materials = 0;
+    int32_t bvh_nodes = 0, bvh_depth = 0;
+
+    // framebuffer
+    int32_t width = 0, height = 0;
+    bool owns_fb = false;
+    void* d_accum = nullptr;
+    void* d_counts = nullptr;
+    void* d_bgra = nullptr;
+    int32_t* d_primary_ids = nullptr;
+    uint32_t* d_path_hash = nullptr;
+    uint32_t* d_counters = nullptr;  // 48 x u32, see FrameArgs::counters
+    uint32_t* h_abort = nullptr;     // pinned host word the pooled kernel sets when it gave up (FrameArgs::abort_flag)
+    // tile order fed back from frame to frame (see FrameArgs::tile_order)
+    uint32_t* d_tile_order = nullptr;
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t tile_capacity = 0;
+    bool order_ready = false;                   // d_tile_order holds the order made from the last frame
+    int32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // width, height, strip_rows, strip_count, strip_index, tiles it was made for
+    // choice between the pooled and the single kernel by measurement (see rt_render_frame)
+    int32_t scene_generation = 0;
+    int32_t tune_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int tune_stage = 0;  // frames of this configuration so far (saturating): 0-2 pooled, 3-4 single, then the choice
+    bool tune_decided = false;
+    hipEvent_t ev_trial[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [pooled, single][begin, end] of the timed trial frames
+    int tune_choice = RT_PIPELINE_POOLED;
+
+    // device memory of the pooled pipeline (allocated on first use, grown when needed)
+    void* d_pool = nullptr;
+    size_t pool_bytes = 0;
+
+    // row-strip exchange (rt_strip_pack / rt_strip_unpack): nothing owned here, see rt_group.hip
+
+    std::string err;
+};
+
+namespace rtapi {
+int fail(RtContext* ctx, int code, const std::string& msg);
+// after a stream synchronise: RT_ERR_HIP (once) if a pooled frame was abandoned since the last report
+int check_abandoned(RtContext* c);
+}  // namespace rtapi
+
+#define RT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return rtapi::fail((ctx), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)

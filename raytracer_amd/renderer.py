@@ -236,6 +236,24 @@ class Context:
     def upload_scene(self, scene: Scene):
         self._chk(self._lib.rt_upload_scene_from(self._h, scene.handle), "rt_upload_scene_from")
 
+    def upload_arrays(self, arrays: dict, n_spheres: int, n_lights: int, n_triangles: int, n_meshes: int):
+        """rt_upload_scene with explicit element counts on byte arrays in the shader's buffer layouts
+        (as Scene.arrays() returns them): for scenes the builder calls cannot express."""
+        a = {k: np.ascontiguousarray(v, dtype=np.uint8) for k, v in arrays.items()}
+        self._keep = a
+
+        def ptr(name, ctype):
+            return C.cast(a[name].ctypes.data_as(C.c_void_p), C.POINTER(ctype))
+
+        self._chk(self._lib.rt_upload_scene(
+            self._h, ptr("spheres", capi.RtSphere), int(n_spheres), ptr("materials", capi.RtMaterial), a["materials"].size // 80,
+            ptr("lights", capi.RtLight), int(n_lights), ptr("triangles", capi.RtTriangle), int(n_triangles),
+            ptr("vertices", capi.RtVertex), a["vertices"].size // 16, ptr("indices", C.c_uint32), a["indices"].size // 4,
+            ptr("meshes", capi.RtMeshInfo), int(n_meshes)), "rt_upload_scene")
+
+    def set_option(self, option: int, value: int):
+        self._chk(self._lib.rt_set_option(self._h, int(option), int(value)), "rt_set_option")
+
     def resize(self, width: int, height: int):
         self._chk(self._lib.rt_resize(self._h, int(width), int(height)), "rt_resize")
         self.width, self.height = int(width), int(height)

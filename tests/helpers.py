@@ -11,6 +11,34 @@ from raytracer_amd.renderer import Context, Scene, default_camera, make_params
 DEBUG_FLAGS = capi.RT_FLAG_PRIMARY_IDS | capi.RT_FLAG_PATH_HASH
 
 
+class ArrayScene:
+    """A built scene whose mesh buffers (vertices, indices, meshes) were replaced by hand: what the
+    reference's Scene could only get from a .glb file.  Quacks like renderer.Scene for the helpers."""
+
+    def __init__(self, base: Scene, vertices, indices, meshes):
+        self.base = base
+        self._arrays = base.arrays()
+        v = np.zeros((len(vertices), 4), np.float32)
+        v[:, :3] = vertices
+        self._arrays["vertices"] = v.view(np.uint8).reshape(-1)
+        self._arrays["indices"] = np.asarray(indices, np.uint32).view(np.uint8).reshape(-1)
+        m = np.asarray(meshes, np.int64).astype(np.uint32).reshape(-1, 3)  # (index_start, index_end, material)
+        self._arrays["meshes"] = m.view(np.uint8).reshape(-1)
+        self.total_meshes = len(m)
+
+    def arrays(self):
+        return dict(self._arrays)
+
+    def push_constants(self, time=0.0, frame_count=0, reset=False):
+        pc = self.base.push_constants(time, frame_count, reset)
+        pc.total_meshes = self.total_meshes
+        return pc
+
+    def upload(self, ctx: Context):
+        v = self.base.view()
+        ctx.upload_arrays(self._arrays, v.total_spheres, v.total_lights, v.total_triangles, self.total_meshes)
+
+
 def oracle_frames(scene: Scene, width, height, spp, max_bounces, frames=1, math_mode=0, camera=None, time=0.0,
                   threads=8, strip=(0, 1, 0), skybox=0):
     cam = camera or default_camera(width, height)
@@ -44,7 +72,7 @@ def gpu_frames(ctx: Context, scene: Scene, width, height, spp, max_bounces, fram
                camera=None, time=0.0, flags=DEBUG_FLAGS, strip=(0, 1, 0), upload=True, resize=True, skybox=0):
     cam = camera or default_camera(width, height)
     if upload:
-        ctx.upload_scene(scene)
+        scene.upload(ctx) if hasattr(scene, "upload") else ctx.upload_scene(scene)
     if resize:
         ctx.resize(width, height)
     total_rays = 0

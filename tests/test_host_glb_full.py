@@ -201,7 +201,8 @@ def test_general_reader_agrees_with_the_reference_reader_on_the_shipped_assets()
             assert not np.allclose(va, vb)
 
 
-@pytest.mark.parametrize("breakage", ["index_out_of_range", "stride_too_small", "view_beyond_bin", "cycle", "no_triangles"])
+@pytest.mark.parametrize("breakage", ["index_out_of_range", "stride_too_small", "view_beyond_bin", "cycle", "no_triangles",
+                                      "huge_count", "huge_count_strided", "negative_offset", "nan_count"])
 def test_general_reader_rejects_malformed_files(tmp_path, breakage):
     pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     idx = np.array([0, 1, 2], np.uint16)
@@ -221,6 +222,15 @@ def test_general_reader_rejects_malformed_files(tmp_path, breakage):
         nodes = [{"mesh": 0, "children": [1]}, {"children": [0]}]
     elif breakage == "no_triangles":
         prim["mode"] = 0
+    elif breakage == "huge_count":          # count * element size would wrap a 64-bit product
+        accessors[1]["count"] = 2 ** 63 + 3
+    elif breakage == "huge_count_strided":  # (count - 1) * stride + element would wrap and pass a multiplied check
+        accessors[0]["count"] = 2 ** 61 + 1
+        views[0]["byteStride"] = 16
+    elif breakage == "negative_offset":
+        accessors[0]["byteOffset"] = -12
+    elif breakage == "nan_count":
+        accessors[1]["count"] = 1e400       # reads as infinity
     doc = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": nodes, "meshes": [{"primitives": [prim]}],
            "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
     write_glb(tmp_path / "bad.glb", doc, blob)
@@ -231,3 +241,10 @@ def test_general_reader_rejects_malformed_files(tmp_path, breakage):
     assert e.value.code == capi.RT_ERR_IO
     # like the reference (scene.cpp:812-814) the scene still gets an (empty) mesh entry
     assert s.view().total_meshes == 1
+    if breakage in ("huge_count", "huge_count_strided", "negative_offset", "nan_count"):
+        # the reference-style reader (mesh 0 / primitive 0) refuses the same numbers
+        s2 = Scene(capi.RT_SCENE_EMPTY, assets_dir=str(tmp_path))
+        m2 = s2.add_material(*GREY)
+        with pytest.raises(RtError) as e2:
+            s2.add_model("bad.glb", (0, 0, 0), 0, 0, 0, 1.0, m2)
+        assert e2.value.code == capi.RT_ERR_IO

@@ -41,8 +41,9 @@ def test_hash_and_xorshift_known_values():
     seq = [270369, 67634689, 2647435461, 307599695]
     s = 1
     for want in seq:
+        mine = py_xorshift(s)  # the same step in Python integers
         s = lib.rto_xorshift(s)
-        assert s == want == py_xorshift(s if False else s) or s == want
+        assert s == want and mine == want
     assert lib.rto_xorshift(0) == 0  # state 0 is a fixed point
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random small configurations (size, samples, bounces, strips, skybox, scene, frames) rendered by the
-single kernel, the pooled kernel, the staged pipeline and the library's own choice; all outputs must
+single kernel, the pooled kernel and the library's own choice; all outputs must
 be bit-identical, and the flat-search run must match the CPU oracle.
     python tools/fuzz_pipelines.py [cases] [seed]"""
 import os, random, sys
@@ -28,7 +28,7 @@ for k in range(cases):
     kw = dict(spp=spp, max_bounces=mb, frames=frames, strip=strip, skybox=sky)
     ref = gpu_frames(ctx, s, W, H, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_SINGLE_KERNEL, **kw)
     ok = True
-    for label, fl in (("pooled", capi.RT_FLAG_POOLED), ("staged", capi.RT_FLAG_WAVEFRONT), ("auto", 0),
+    for label, fl in (("pooled", capi.RT_FLAG_POOLED), ("auto", 0),
                       ("pooled, image order", capi.RT_FLAG_POOLED | capi.RT_FLAG_FIXED_TILE_ORDER)):
         g = gpu_frames(ctx, s, W, H, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | fl, **kw)
         same = (bit_equal_pixels(g["accum"], ref["accum"]).all() and np.array_equal(g["counts"], ref["counts"]) and

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Render N frames of a workload (for profilers).  python tools/run_frames.py c3 4 [single|staged|pooled|auto] [stats]"""
+"""Render N frames of a workload (for profilers).  python tools/run_frames.py c3 4 [single|pooled|auto] [stats]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import capi
@@ -8,7 +8,7 @@ from raytracer_amd.workloads import WORKLOADS, workload_camera
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 mode = sys.argv[3] if len(sys.argv) > 3 else "single"
-flags = {"staged": capi.RT_FLAG_WAVEFRONT, "pooled": capi.RT_FLAG_POOLED, "single": capi.RT_FLAG_SINGLE_KERNEL, "auto": 0}[mode]
+flags = {"pooled": capi.RT_FLAG_POOLED, "single": capi.RT_FLAG_SINGLE_KERNEL, "auto": 0}[mode]
 if len(sys.argv) > 4 and sys.argv[4] == "stats":
     flags |= capi.RT_FLAG_TRAVERSAL_STATS
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
