@@ -550,14 +550,13 @@ __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __r
                                                                    const uint32_t k5, const uint32_t k6, const uint32_t k7) {
     extern __shared__ uint8_t s_class[];                     // [n]
     __shared__ uint32_t s_max;
-    __shared__ uint32_t s_count[kMaxClasses * kOrderWaves];  // [class][wave]: tiles of the class in the wave's range, then their first position
+    __shared__ uint32_t s_count[kMaxClasses * kOrderWaves];  // [class][wave]: tiles of the class in the wave's range -> their first position
     __shared__ uint32_t s_wave[kOrderWaves];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_max = 0;
-    for (uint32_t e = tid; e < (uint32_t)(kMaxClasses * kOrderWaves); e += kOrderThreads) s_count[e] = 0;
     __syncthreads();
     uint32_t m = 0;
-#pragma unroll 8
+#pragma unroll 16
     for (uint32_t i = tid; i < n; i += kOrderThreads) m = cost[i] > m ? cost[i] : m;
     for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = __shfl_xor(m, off);
@@ -576,10 +575,12 @@ __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __r
         cost[i] = 0u;
     }
     __syncthreads();
-    // a wave's range: whole groups of 64 tiles
+    // a wave's range: whole groups of 64 tiles.  Lane c of a wave keeps the wave's running count (then
+    // position) of class c in a register, so that the walk needs no LDS round trip per class.
     const uint32_t groups = (n + 63u) / 64u, per_wave = (groups + kOrderWaves - 1u) / kOrderWaves;
     const uint32_t g_begin = wave * per_wave < groups ? wave * per_wave : groups;
     const uint32_t g_end = g_begin + per_wave < groups ? g_begin + per_wave : groups;
+    uint32_t run = 0;  // lane c: tiles of class c seen so far in this wave's range / next position of class c
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t g = g_begin; g < g_end; ++g) {
             const uint32_t i = g * 64u + lane;
@@ -589,17 +590,17 @@ __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __r
                 const int lead = __ffsll((long long)left) - 1;
                 const int cc = __builtin_amdgcn_readlane(c, lead);
                 const unsigned long long same = __ballot(c == cc);
-                uint32_t* const slot = &s_count[cc * kOrderWaves + (int)wave];
                 if (pass == 1) {
-                    const uint32_t at = *(volatile uint32_t*)slot;
+                    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run, cc);
                     if (c == cc) order[at + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
                 }
-                if ((int)lane == lead) *(volatile uint32_t*)slot += (uint32_t)__popcll(same);
+                if ((int)lane == cc) run += (uint32_t)__popcll(same);
                 left &= ~same;
             }
         }
         if (pass == 0) {
-            // exclusive scan of s_count in [class][wave] order = first position of each (class, wave) run
+            // exclusive scan of the counts in [class][wave] order = first position of each (class, wave) run
+            s_count[lane * kOrderWaves + wave] = run;
             __syncthreads();
             const uint32_t v = s_count[tid];
             uint32_t inc = v;
@@ -613,6 +614,7 @@ __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __r
             for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
             s_count[tid] = before + inc - v;
             __syncthreads();
+            run = s_count[lane * kOrderWaves + wave];
         }
     }
     if (stamp != nullptr && tid < 8u) {
@@ -622,7 +624,7 @@ __global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __r
         stamp[tid] = v;  // read by later launches on the same stream only
     }
 }
-static_assert(kMaxClasses * kOrderWaves == kOrderThreads, "one thread per (class, wave) count in the scan");
+static_assert(kMaxClasses * kOrderWaves == kOrderThreads && kMaxClasses == 64, "one lane per class, one thread per (class, wave) count in the scan");
 
 __global__ void __launch_bounds__(256) tile_order_check_kernel(uint32_t* __restrict__ order, uint32_t n, const uint32_t* __restrict__ stamp,
                                                               const uint32_t k0, const uint32_t k1, const uint32_t k2, const uint32_t k3,
