@@ -227,6 +227,21 @@ int rt_bind_framebuffer(RtContext* ctx, int32_t width, int32_t height,
 int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pc,
                     const RtParams* params);
 
+/* rt_render_frame for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same frame, same bits,
+ * but the framebuffer comes as arguments (device memory, width*height float4 / int32 / BGRA8, aligned
+ * 16/4/4, contents kept as rt_render_frame keeps them) and everything else the frame needs (tile order,
+ * the pooled kernel's slot records and stack overflow) lives in a fixed 47 MiB device array inside the
+ * library instead of memory allocated on demand: the call makes no hipMalloc / hipFree and waits for
+ * nothing.  Limits: at most 131072 tiles of 8x8 pixels (8.39 M pixels) -> RT_ERR_TOO_LARGE;
+ * RT_FLAG_PRIMARY_IDS / RT_FLAG_PATH_HASH -> RT_ERR_UNSUPPORTED (their buffers are allocated on
+ * demand); no timed trial between the kernels (BVH frames of >= 16384 pixels run pooled, others
+ * single, the flags force either).  All calls on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU (two contexts, two threads) race and must be serialised by the caller. */
+int rt_render_frame_noalloc(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pc,
+                            const RtParams* params, void* d_accum_float4, void* d_counts_int32,
+                            void* d_bgra8, int32_t width, int32_t height);
+
 /* Recompute the BGRA8 image from the accumulation buffers (raytracer.comp:992-995) after
  * they were combined across GPUs. */
 int rt_resolve(RtContext* ctx);

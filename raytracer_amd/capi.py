@@ -146,6 +146,8 @@ PROTOTYPES = {
     "rt_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "rt_bind_framebuffer": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     "rt_render_frame": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams)]),
+    "rt_render_frame_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), _P, _P, _P,
+                                          C.c_int32, C.c_int32]),
     "rt_resolve": (C.c_int, [_P]),
     "rt_read_output_bgra8": (C.c_int, [_P, _P]),
     "rt_read_accum": (C.c_int, [_P, _P, _P]),

@@ -49,7 +49,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of kWaves, <= 4096)
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
-constexpr int kOverflow = kStackDepth;  // entries per lane of the overflow area
+constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
 enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_LIGHT = 3, Q_END = 4, kQueues = 5 };
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;

@@ -36,7 +36,23 @@ int check_abandoned(RtContext* c) {
 }  // namespace rtapi
 using rtapi::fail;
 
+// ---------------------------------------------------------------------------------------------
+// Scratch memory of rt_render_frame_noalloc: what a frame needs beyond its inputs and outputs (the
+// tile order fed back from call to call and the pooled kernel's slot records and stack overflow), in a
+// file-scope device array instead of hipMalloc'd memory.  Every GPU the library runs on holds its
+// own copy at its own address until the process ends; the array's name is only a host-side stand-in
+// for it, so host code uses the address hipGetSymbolAddress returns for the current device
+// (g_scratch_ptr, taken once per device in rt_create) wherever the memory is meant.
 namespace {
+constexpr size_t kScratchTiles = 128u * 1024u;      // 8x8 tiles of the largest frame (8.39 M pixels, e.g. 3840 x 2184)
+constexpr size_t kScratchStampBytes = 256;          // 8 words: what the stored tile order was made for
+constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1408 x 64 B records + 1024 x 24 stack words)
+constexpr size_t kScratchBytes = kScratchStampBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 256 B
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+namespace {
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device: the address of its copy of `scratch`
 
 // Device memory a frame needs beyond the scene and the framebuffer.
 struct FrameScratch {
@@ -159,6 +175,16 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
         return fail(nullptr, RT_ERR_HIP, "stream/event/counter creation failed");
     }
     *c->h_abort = 0u;
+    // this device's copy of the no-allocation scratch array (the device is current since hipSetDevice above)
+    if (device_ordinal < kMaxDevices && g_scratch_ptr[device_ordinal] == nullptr) {
+        void* sp = nullptr;
+        hipError_t es = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (es != hipSuccess || sp == nullptr) {
+            rt_destroy(c);
+            return fail(nullptr, RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(es));
+        }
+        g_scratch_ptr[device_ordinal] = (unsigned char*)sp;
+    }
     // tuning aids: the environment may override an option's default, read once here
     struct { const char* name; int option; } env[] = {
         {"RT_EXIT_QUOTA_PCT", RT_OPT_EXIT_QUOTA_PCT}, {"RT_REFILL_MIN", RT_OPT_REFILL_MIN}, {"RT_POOL_BURST", RT_OPT_POOL_BURST},
@@ -507,6 +533,68 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
         RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, c->opt.tile_classes, nullptr, nullptr, c->stream));
         c->order_ready = true;
     }
+    return RT_OK;
+}
+
+int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, void* d_accum,
+                            void* d_counts, void* d_bgra, int32_t width, int32_t height) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28) || !d_accum || !d_counts || !d_bgra)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "bad framebuffer");
+    if (((uintptr_t)d_accum & 15u) || ((uintptr_t)d_counts & 3u) || ((uintptr_t)d_bgra & 3u))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "framebuffer pointers must be 16/4/4-byte aligned");
+    RtParams p;
+    rtd::DeviceScene sc;
+    rtd::FrameArgs fa;
+    int rc = prepare_frame(c, camera, pc, params, width, height, p, sc, fa);
+    if (rc != RT_OK) return rc;
+    if (p.flags & (RT_FLAG_PRIMARY_IDS | RT_FLAG_PATH_HASH))
+        return fail(c, RT_ERR_UNSUPPORTED, "the debug outputs live in buffers this call may not allocate; use rt_render_frame");
+    const uint32_t n_tiles = fa.total_slots >> rtd::kBlockSlotsLog2;
+    if (n_tiles > kScratchTiles)
+        return fail(c, RT_ERR_TOO_LARGE, "rt_render_frame_noalloc renders at most 131072 tiles of 8x8 pixels (8.39 M pixels) per call");
+    if (c->device >= kMaxDevices || g_scratch_ptr[c->device] == nullptr) return fail(c, RT_ERR_HIP, "no scratch memory on this device");
+    fa.accum = (float4*)d_accum;
+    fa.counts = (int32_t*)d_counts;
+    fa.bgra = (uint32_t*)d_bgra;
+
+    RT_HIP(c, hipSetDevice(c->device));
+    unsigned char* const base = g_scratch_ptr[c->device];
+    uint32_t* const stamp = (uint32_t*)base;
+    uint32_t* const tile_cost = (uint32_t*)(base + kScratchStampBytes);
+    uint32_t* const tile_order = tile_cost + kScratchTiles;
+    void* const pool = base + kScratchStampBytes + 2 * 4 * kScratchTiles;
+
+    // The tile order of the previous call is kept in the scratch array together with a stamp of what it
+    // was made for; a kernel compares the stamp with this call's key and falls back to image order, so
+    // that no host state is involved and a call of another size (or another context) cannot misuse it.
+    const bool feedback = !(p.flags & RT_FLAG_FIXED_TILE_ORDER) && n_tiles > 0;
+    const uint32_t key[8] = {0x7231746fu, (uint32_t)fa.width, (uint32_t)fa.height, (uint32_t)fa.strip_rows, (uint32_t)fa.strip_count,
+                             (uint32_t)fa.strip_index, n_tiles, (uint32_t)c->opt.tile_classes};
+    if (feedback) {
+        RT_HIP(c, hipMemsetAsync(tile_cost, 0, (size_t)n_tiles * 4, c->stream));  // whatever the last call left
+        RT_HIP(c, rtd::launch_tile_order_check(tile_order, n_tiles, stamp, key, c->stream));
+        fa.tile_cost = tile_cost;
+        fa.tile_order = tile_order;
+    }
+    int pipeline = RT_PIPELINE_SINGLE;
+    if (p.flags & RT_FLAG_POOLED) {
+        if (!pooled_fits(c, p))
+            return fail(c, RT_ERR_TOO_LARGE, "the pooled pipeline holds at most 65535 samples, 65534 bounces, 32768 lights and 65536 materials");
+        pipeline = RT_PIPELINE_POOLED;
+    } else if (!(p.flags & RT_FLAG_SINGLE_KERNEL) && p.accel == RT_ACCEL_BVH && pooled_fits(c, p) && fa.total_slots >= 16384u) {
+        pipeline = RT_PIPELINE_POOLED;  // no timed trial here: the pooled kernel wins on most frames
+    }
+    unsigned grid = 0;
+    if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
+        RT_HIP(c, rtd::pool_grid(fa, p.accel, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, c->cu_count, c->opt.pool_per_cu, &grid));
+        const unsigned fits = (unsigned)(kScratchPoolBytes / pooled_pool_bytes(1));
+        grid = grid > fits ? fits : grid;  // fewer workgroups than CUs still render the whole frame
+    }
+    rc = launch_frame(c, sc, fa, p, pipeline, grid, pool);
+    if (rc != RT_OK) return rc;
+    if (feedback && fa.total_slots > 0)
+        RT_HIP(c, rtd::launch_tile_order(tile_cost, tile_order, n_tiles, c->opt.tile_classes, stamp, key, c->stream));
     return RT_OK;
 }
 

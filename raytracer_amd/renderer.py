@@ -267,6 +267,11 @@ class Context:
         self._chk(self._lib.rt_render_frame(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None),
                   "rt_render_frame")
 
+    def render_frame_noalloc(self, camera, pc, params, accum_ptr: int, counts_ptr: int, bgra_ptr: int, width: int, height: int):
+        self._chk(self._lib.rt_render_frame_noalloc(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None,
+                                                    C.c_void_p(accum_ptr), C.c_void_p(counts_ptr), C.c_void_p(bgra_ptr),
+                                                    int(width), int(height)), "rt_render_frame_noalloc")
+
     def resolve(self):
         self._chk(self._lib.rt_resolve(self._h), "rt_resolve")
 
