@@ -231,7 +231,7 @@ int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstant
  * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same frame, same bits,
  * but the framebuffer comes as arguments (device memory, width*height float4 / int32 / BGRA8, aligned
  * 16/4/4, contents kept as rt_render_frame keeps them) and everything else the frame needs (tile order,
- * the pooled kernel's slot records and stack overflow) lives in a fixed 47 MiB device array inside the
+ * the pooled kernel's slot records and stack overflow) lives in a fixed 47.2 MiB device array inside the
  * library instead of memory allocated on demand: the call makes no hipMalloc / hipFree and waits for
  * nothing.  Limits: at most 131072 tiles of 8x8 pixels (8.39 M pixels) -> RT_ERR_TOO_LARGE;
  * RT_FLAG_PRIMARY_IDS / RT_FLAG_PATH_HASH -> RT_ERR_UNSUPPORTED (their buffers are allocated on

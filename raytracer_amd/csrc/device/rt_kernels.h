@@ -104,10 +104,12 @@ hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPoo
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 // Turns the per-tile costs of the frame just rendered into the next frame's tile order (most
 // expensive class first, image order within a class) and clears the costs.  At most
-// tile_order_max_tiles() tiles.  `stamp` (may be null): 8 words that receive `key` once the order is
-// written, so that a later launch_tile_order_check can tell what the order was made for.
+// tile_order_max_tiles() tiles.  `aux`: tile_order_aux_bytes() bytes of work area whose first word is zero
+// before the first call (every call leaves it zero again).  `stamp` (may be null): 8 words that receive
+// `key` once the order is written, so that a later launch_tile_order_check can tell what the order was made for.
 uint32_t tile_order_max_tiles();
-hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* stamp,
+size_t tile_order_aux_bytes();
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* aux, uint32_t* stamp,
                              const uint32_t key[8], hipStream_t stream);
 // Replaces tile_order by the identity unless `stamp` holds `key` (device-side check: no host state).
 hipError_t launch_tile_order_check(uint32_t* tile_order, uint32_t n_tiles, const uint32_t* stamp, const uint32_t key[8],

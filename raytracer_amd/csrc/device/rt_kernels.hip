@@ -533,98 +533,122 @@ namespace {
 constexpr int kOrderThreads = 1024;
 constexpr int kOrderWaves = kOrderThreads / 64;
 constexpr int kMaxClasses = 64;
-constexpr uint32_t kOrderMaxTiles = 128u * 1024u;  // one class byte per tile in LDS
+constexpr uint32_t kOrderMaxTiles = 128u * 1024u;
+constexpr uint32_t kOrderMaxGroups = kOrderMaxTiles / kOrderThreads;  // workgroups: one tile per thread
+// Work area of the three kernels: word 0 = the dearest tile's cost (zero between calls), from byte 256 the
+// table of tiles per (class, workgroup), then one class byte per tile.
+constexpr size_t kOrderAuxTable = 256, kOrderAuxClass = kOrderAuxTable + (size_t)kMaxClasses * kOrderMaxGroups * 4;
+constexpr size_t kOrderAuxBytes = kOrderAuxClass + kOrderMaxTiles;
 
-// One workgroup, three sweeps.  Tiles are put into `classes` classes by cost relative to the dearest
-// tile and listed class by class, dearest first, in image order within a class (neighbouring tiles
-// stay neighbours: their rays share nodes and materials).  Long pixels thus start early and the
-// frame ends on short ones.  The costs are cleared for the next frame.
-//   sweep 1: the dearest tile (coalesced loads, many in flight);
-//   sweep 2: every tile's class into LDS (one byte per tile);
-//   sweep 3, twice: each wave walks a contiguous range of tiles 64 at a time and ranks the lanes of
-//            each class present with one ballot - first to count (per wave and class), then, after
-//            one scan of the kOrderWaves x classes counts, to place.
-__global__ void __launch_bounds__(kOrderThreads) tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n,
-                                                                   int classes, uint32_t* __restrict__ stamp, const uint32_t k0,
-                                                                   const uint32_t k1, const uint32_t k2, const uint32_t k3, const uint32_t k4,
-                                                                   const uint32_t k5, const uint32_t k6, const uint32_t k7) {
-    extern __shared__ uint8_t s_class[];                     // [n]
-    __shared__ uint32_t s_max;
-    __shared__ uint32_t s_count[kMaxClasses * kOrderWaves];  // [class][wave]: tiles of the class in the wave's range -> their first position
-    __shared__ uint32_t s_wave[kOrderWaves];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_max = 0;
+// Exclusive prefix sum of one value per thread over the workgroup (kOrderThreads threads).
+RT_DEV uint32_t order_block_scan(uint32_t v, uint32_t* s_wave) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += up;
+    }
+    __syncthreads();  // s_wave may still be read from an earlier call
+    if (lane == 63u) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t m = 0;
-#pragma unroll 16
-    for (uint32_t i = tid; i < n; i += kOrderThreads) m = cost[i] > m ? cost[i] : m;
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    return before + inc - v;
+}
+
+// The frame's tiles are put into `classes` classes by cost relative to the dearest tile and listed class
+// by class, dearest first, in image order within a class (neighbouring tiles stay neighbours: their rays
+// share nodes and materials).  Long pixels thus start early and the frame ends on short ones.  Three
+// launches of one tile per thread (one workgroup took 50 us for a 1080p frame: it is instruction-bound):
+// the dearest tile; every tile's class and the tiles per (class, workgroup); the placement.
+
+__global__ void __launch_bounds__(kOrderThreads) tile_max_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ aux) {
+    __shared__ uint32_t s_max;
+    const uint32_t i = blockIdx.x * kOrderThreads + threadIdx.x;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    uint32_t m = i < n ? cost[i] : 0u;
     for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = __shfl_xor(m, off);
         m = o > m ? o : m;
     }
-    if (lane == 0) atomicMax(&s_max, m);
+    if ((threadIdx.x & 63u) == 0u) atomicMax(&s_max, m);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&aux[0], s_max);
+}
+
+__global__ void __launch_bounds__(kOrderThreads) tile_class_kernel(uint32_t* __restrict__ cost, uint32_t n, int classes, uint32_t* __restrict__ aux) {
+    __shared__ uint32_t s_hist[kMaxClasses];
+    const uint32_t i = blockIdx.x * kOrderThreads + threadIdx.x;
+    if (threadIdx.x < (uint32_t)kMaxClasses) s_hist[threadIdx.x] = 0;
     __syncthreads();
     // class = classes - 1 - floor(cost * classes / (max + 1)) in binary32 (monotonic in the cost, which is all
-    // the order needs; an integer division would cost more than the rest of the kernel)
-    const float per_cost = (float)classes / ((float)s_max + 1.0f);
-#pragma unroll 8
-    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+    // the order needs)
+    const float per_cost = (float)classes / ((float)aux[0] + 1.0f);
+    if (i < n) {
         int c = (int)((float)cost[i] * per_cost);
-        c = c > classes - 1 ? classes - 1 : c;
-        s_class[i] = (uint8_t)(classes - 1 - c);
-        cost[i] = 0u;
+        c = classes - 1 - (c > classes - 1 ? classes - 1 : c);
+        ((uint8_t*)aux + kOrderAuxClass)[i] = (uint8_t)c;
+        cost[i] = 0u;  // cleared for the next frame
+        atomicAdd(&s_hist[c], 1u);
     }
     __syncthreads();
-    // a wave's range: whole groups of 64 tiles.  Lane c of a wave keeps the wave's running count (then
-    // position) of class c in a register, so that the walk needs no LDS round trip per class.
-    const uint32_t groups = (n + 63u) / 64u, per_wave = (groups + kOrderWaves - 1u) / kOrderWaves;
-    const uint32_t g_begin = wave * per_wave < groups ? wave * per_wave : groups;
-    const uint32_t g_end = g_begin + per_wave < groups ? g_begin + per_wave : groups;
-    uint32_t run = 0;  // lane c: tiles of class c seen so far in this wave's range / next position of class c
-    for (int pass = 0; pass < 2; ++pass) {
-        for (uint32_t g = g_begin; g < g_end; ++g) {
-            const uint32_t i = g * 64u + lane;
-            const int c = i < n ? (int)s_class[i] : -1;
-            unsigned long long left = __ballot(c >= 0);
-            while (left != 0ull) {
-                const int lead = __ffsll((long long)left) - 1;
-                const int cc = __builtin_amdgcn_readlane(c, lead);
-                const unsigned long long same = __ballot(c == cc);
-                if (pass == 1) {
-                    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run, cc);
-                    if (c == cc) order[at + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
-                }
-                if ((int)lane == cc) run += (uint32_t)__popcll(same);
-                left &= ~same;
-            }
-        }
-        if (pass == 0) {
-            // exclusive scan of the counts in [class][wave] order = first position of each (class, wave) run
-            s_count[lane * kOrderWaves + wave] = run;
-            __syncthreads();
-            const uint32_t v = s_count[tid];
-            uint32_t inc = v;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(inc, off);
-                if ((int)lane >= off) inc += up;
-            }
-            if (lane == 63u) s_wave[wave] = inc;
-            __syncthreads();
-            uint32_t before = 0;
-            for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
-            s_count[tid] = before + inc - v;
-            __syncthreads();
-            run = s_count[lane * kOrderWaves + wave];
-        }
+    if (threadIdx.x < (uint32_t)kMaxClasses)
+        (aux + kOrderAuxTable / 4)[threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kOrderThreads) tile_place_kernel(uint32_t* __restrict__ order, uint32_t n, uint32_t* __restrict__ aux,
+                                                                   uint32_t* __restrict__ stamp, const uint32_t k0, const uint32_t k1,
+                                                                   const uint32_t k2, const uint32_t k3, const uint32_t k4, const uint32_t k5,
+                                                                   const uint32_t k6, const uint32_t k7) {
+    __shared__ uint32_t s_first[kMaxClasses];                // first position of this workgroup's tiles of each class
+    __shared__ uint32_t s_count[kMaxClasses * kOrderWaves];  // [class][wave]: tiles of the class in the wave -> their rank in the workgroup
+    __shared__ uint32_t s_wave[kOrderWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    s_count[tid] = 0;
+    // positions before this workgroup's tiles of class c = exclusive prefix of the (class, workgroup) table,
+    // in that order, at entry (c, g)
+    const uint32_t* const table = aux + kOrderAuxTable / 4;
+    const uint32_t entries = (uint32_t)kMaxClasses * G, per = (entries + kOrderThreads - 1u) / kOrderThreads;
+    const uint32_t e_begin = tid * per < entries ? tid * per : entries, e_end = e_begin + per < entries ? e_begin + per : entries;
+    uint32_t mine = 0;
+    for (uint32_t e = e_begin; e < e_end; ++e) mine += table[e];
+    uint32_t prefix = order_block_scan(mine, s_wave);
+    for (uint32_t e = e_begin; e < e_end; ++e) {
+        if (e % G == g) s_first[e / G] = prefix;
+        prefix += table[e];
     }
-    if (stamp != nullptr && tid < 8u) {
+    // every lane finds the lanes of its wave with its own class by six ballots (one per bit of the class):
+    // its rank among them, and their number
+    const uint32_t i = g * kOrderThreads + tid;
+    const bool valid = i < n;
+    const uint32_t c = valid ? (uint32_t)((const uint8_t*)aux + kOrderAuxClass)[i] : 0u;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+        const bool set = ((c >> bit) & 1u) != 0u;
+        const unsigned long long m = __ballot(set);
+        same &= set ? m : ~m;
+    }
+    const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_count zeroed, s_first written
+    if (valid && rank == 0u) s_count[c * kOrderWaves + wave] = (uint32_t)__popcll(same);
+    __syncthreads();
+    const uint32_t scanned = order_block_scan(s_count[tid], s_wave);  // [class][wave] order
+    __syncthreads();
+    s_count[tid] = scanned;
+    __syncthreads();
+    if (valid) order[s_first[c] + (s_count[c * kOrderWaves + wave] - s_count[c * kOrderWaves]) + rank] = i;
+    if (g == 0u && tid == 0u) aux[0] = 0u;  // no workgroup of this launch reads it
+    if (stamp != nullptr && g == 0u && tid < 8u) {
         const uint32_t k[8] = {k0, k1, k2, k3, k4, k5, k6, k7};
         uint32_t v = k[0];
         for (uint32_t j = 1; j < 8u; ++j) v = (tid == j) ? k[j] : v;
         stamp[tid] = v;  // read by later launches on the same stream only
     }
 }
-static_assert(kMaxClasses * kOrderWaves == kOrderThreads && kMaxClasses == 64, "one lane per class, one thread per (class, wave) count in the scan");
+static_assert(kMaxClasses * kOrderWaves == kOrderThreads && kMaxClasses == 64, "one thread per (class, wave) count in the scan; six class bits");
 
 __global__ void __launch_bounds__(256) tile_order_check_kernel(uint32_t* __restrict__ order, uint32_t n, const uint32_t* __restrict__ stamp,
                                                               const uint32_t k0, const uint32_t k1, const uint32_t k2, const uint32_t k3,
@@ -639,16 +663,20 @@ __global__ void __launch_bounds__(256) tile_order_check_kernel(uint32_t* __restr
 }  // namespace
 
 uint32_t tile_order_max_tiles() { return kOrderMaxTiles; }
+size_t tile_order_aux_bytes() { return kOrderAuxBytes; }
 
-hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* stamp,
+hipError_t launch_tile_order(uint32_t* tile_cost, uint32_t* tile_order, uint32_t n_tiles, int classes, uint32_t* aux, uint32_t* stamp,
                              const uint32_t key[8], hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
-    if (n_tiles > kOrderMaxTiles) return hipErrorInvalidValue;
+    if (n_tiles > kOrderMaxTiles || aux == nullptr) return hipErrorInvalidValue;
     classes = classes < 1 ? 1 : (classes > kMaxClasses ? kMaxClasses : classes);
     static const uint32_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t* k = key ? key : zero;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), (size_t)((n_tiles + 15u) & ~15u), stream, tile_cost, tile_order,
-                       n_tiles, classes, stamp, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]);
+    const dim3 grid((n_tiles + kOrderThreads - 1u) / kOrderThreads), block(kOrderThreads);
+    hipLaunchKernelGGL(tile_max_kernel, grid, block, 0, stream, tile_cost, n_tiles, aux);
+    hipLaunchKernelGGL(tile_class_kernel, grid, block, 0, stream, tile_cost, n_tiles, classes, aux);
+    hipLaunchKernelGGL(tile_place_kernel, grid, block, 0, stream, tile_order, n_tiles, aux, stamp, k[0], k[1], k[2], k[3], k[4], k[5], k[6],
+                       k[7]);
     return hipGetLastError();
 }
 

@@ -46,8 +46,9 @@ using rtapi::fail;
 namespace {
 constexpr size_t kScratchTiles = 128u * 1024u;      // 8x8 tiles of the largest frame (8.39 M pixels, e.g. 3840 x 2184)
 constexpr size_t kScratchStampBytes = 256;          // 8 words: what the stored tile order was made for
+constexpr size_t kScratchAuxBytes = 192u << 10;     // work area of the tile order kernels (rtd::tile_order_aux_bytes() <= this)
 constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1408 x 64 B records + 1024 x 24 stack words)
-constexpr size_t kScratchBytes = kScratchStampBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 256 B
+constexpr size_t kScratchBytes = kScratchStampBytes + kScratchAuxBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 192 KiB + 256 B
 constexpr int kMaxDevices = 64;
 }  // namespace
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -209,6 +210,7 @@ int rt_destroy(RtContext* c) {
         if (c->ev_trial[k >> 1][k & 1]) (void)hipEventDestroy(c->ev_trial[k >> 1][k & 1]);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_aux) (void)hipFree(c->d_tile_aux);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -465,6 +467,10 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
             c->order_ready = false;
             RT_HIP(c, hipMalloc((void**)&c->d_tile_order, (size_t)n_tiles * 4));
             RT_HIP(c, hipMalloc((void**)&c->d_tile_cost, (size_t)n_tiles * 4));
+            if (!c->d_tile_aux) {
+                RT_HIP(c, hipMalloc((void**)&c->d_tile_aux, rtd::tile_order_aux_bytes()));
+                RT_HIP(c, hipMemsetAsync(c->d_tile_aux, 0, 256, c->stream));
+            }
             c->tile_capacity = n_tiles;
         }
         if (!c->order_ready || memcmp(key, c->order_key, sizeof key) != 0) {
@@ -530,7 +536,7 @@ int rt_render_frame(RtContext* c, const RtCamera* camera, const RtPushConstants*
     if (rc != RT_OK) return rc;
     if (trial >= 0) RT_HIP(c, hipEventRecord(c->ev_trial[trial][1], c->stream));
     if (feedback && fa.total_slots > 0) {
-        RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, c->opt.tile_classes, nullptr, nullptr, c->stream));
+        RT_HIP(c, rtd::launch_tile_order(c->d_tile_cost, c->d_tile_order, n_tiles, c->opt.tile_classes, c->d_tile_aux, nullptr, nullptr, c->stream));
         c->order_ready = true;
     }
     return RT_OK;
@@ -561,9 +567,11 @@ int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushCo
     RT_HIP(c, hipSetDevice(c->device));
     unsigned char* const base = g_scratch_ptr[c->device];
     uint32_t* const stamp = (uint32_t*)base;
-    uint32_t* const tile_cost = (uint32_t*)(base + kScratchStampBytes);
+    uint32_t* const tile_aux = (uint32_t*)(base + kScratchStampBytes);  // its first word: zero at load, and after every call
+    uint32_t* const tile_cost = (uint32_t*)(base + kScratchStampBytes + kScratchAuxBytes);
     uint32_t* const tile_order = tile_cost + kScratchTiles;
-    void* const pool = base + kScratchStampBytes + 2 * 4 * kScratchTiles;
+    void* const pool = base + kScratchStampBytes + kScratchAuxBytes + 2 * 4 * kScratchTiles;
+    if (rtd::tile_order_aux_bytes() > kScratchAuxBytes) return fail(c, RT_ERR_HIP, "scratch layout out of date");
 
     // The tile order of the previous call is kept in the scratch array together with a stamp of what it
     // was made for; a kernel compares the stamp with this call's key and falls back to image order, so
@@ -594,7 +602,7 @@ int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushCo
     rc = launch_frame(c, sc, fa, p, pipeline, grid, pool);
     if (rc != RT_OK) return rc;
     if (feedback && fa.total_slots > 0)
-        RT_HIP(c, rtd::launch_tile_order(tile_cost, tile_order, n_tiles, c->opt.tile_classes, stamp, key, c->stream));
+        RT_HIP(c, rtd::launch_tile_order(tile_cost, tile_order, n_tiles, c->opt.tile_classes, tile_aux, stamp, key, c->stream));
     return RT_OK;
 }
 

@@ -53,6 +53,7 @@ struct RtContext {
     // tile order fed back from frame to frame (see FrameArgs::tile_order)
     uint32_t* d_tile_order = nullptr;
     uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_aux = nullptr;  // work area of the tile order kernels
     uint32_t tile_capacity = 0;
     bool order_ready = false;                   // d_tile_order holds the order made from the last frame
     int32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // width, height, strip_rows, strip_count, strip_index, tiles it was made for
