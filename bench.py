@@ -109,8 +109,11 @@ def main() -> None:
     main_stream = torch.cuda.current_stream(dev)
     exchange = None
     if collective and partition == "strips":
-        exchange = parallel.StripExchange([acc, cnt, bgra], H, STRIP_ROWS, world, rank, include_self=args.force_collective)
-    packed = torch.cuda.Event()
+        # one all-gather per frame: colours + counts of own rows packed by the library (20 B per pixel), the
+        # other ranks' rows unpacked and their BGRA8 bytes rebuilt by it
+        exchange = parallel.PackedStripExchange(acc, cnt, bgra, STRIP_ROWS, world, rank, ctx=ctx, include_self=args.force_collective)
+    packed, gathered = torch.cuda.Event(), torch.cuda.Event()
+    pending = [False]  # a gathered frame still waits to be unpacked
 
     def step(frame: int, ev=None) -> None:
         if partition == "samples":
@@ -136,17 +139,26 @@ def main() -> None:
         if ev is not None:
             ev[1].record(rt_stream)
         if collective:
-            # own rows are copied out first; the next frame's kernel (own rows only) may then run
-            # while the all-gather moves the copies and the other ranks' rows are written back
-            main_stream.wait_stream(rt_stream)
+            # Render stream: kernel(N), unpack(N-1), pack(N); collective stream: gather(N) after pack(N).
+            # The all-gather of frame N thus runs beside kernel N+1 (which writes own rows only; the
+            # gather reads the packed copy), and its rows are unpacked once that kernel is through.
+            flush()
             exchange.pack()
-            packed.record(main_stream)
-            rt_stream.wait_event(packed)
-            exchange.exchange()
-            if args.force_collective:  # the one-rank self-test writes its own rows back too
-                rt_stream.wait_stream(main_stream)
+            packed.record(rt_stream)
+            main_stream.wait_event(packed)
+            exchange.gather()
+            gathered.record(main_stream)
+            pending[0] = True
+
+    def flush() -> None:
+        if pending[0]:
+            rt_stream.wait_event(gathered)
+            exchange.unpack()
+            pending[0] = False
 
     def fence() -> None:
+        if collective and partition == "strips":
+            flush()
         ctx.sync()
         torch.cuda.synchronize()
         if collective:
@@ -242,7 +254,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "search": args.accel,
                        "partition": ("single GPU" if not collective else
-                                     f"row strips of {STRIP_ROWS} rows, all-gather" if partition == "strips" else
+                                     f"row strips of {STRIP_ROWS} rows, one all-gather of packed colours + counts per frame" if partition == "strips" else
                                      f"frames of a {FRAMES_PER_BATCH}-frame batch dealt to ranks, all-reduce of accumulators"),
                        "pipeline": pipeline, "frames_per_step": frames_per_step,
                        "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},

@@ -161,7 +161,32 @@ int main(int argc, char** argv) {
         }
         if (rt_read_output_bgra8(ctx, img_b.data()) != RT_OK) throw std::runtime_error(rt_last_error(ctx));
         rt_destroy(ctx);
+
+        // (c) the same frames shared by the GPUs of the node in row strips: RT_DEVICES=n (default 1) devices
+        // 0..n-1, one all-gather over xGMI per frame; every device ends up with the whole picture
+        const char* nd = std::getenv("RT_DEVICES");
+        const int n_dev = nd ? std::atoi(nd) : 1;
+        std::vector<int> ordinals;
+        for (int i = 0; i < (n_dev > 0 ? n_dev : 1); ++i) ordinals.push_back(i);
+        RtGroup* grp = nullptr;
+        if (rt_group_create((int)ordinals.size(), ordinals.data(), &grp) != RT_OK) throw std::runtime_error(rt_last_error(nullptr));
+        if (rt_group_upload_scene_from(grp, built) != RT_OK || rt_group_resize(grp, w, h) != RT_OK) throw std::runtime_error(rt_group_last_error(grp));
+        for (int f = 0; f < frames; ++f) {
+            RtPushConstants pc;
+            rt_push_constants(&pc, built, 0.0f, (uint32_t)f, f == 0);
+            if (rt_group_render_frame(grp, &cam, &pc, &params, RT_GROUP_STRIPS, 9) != RT_OK) throw std::runtime_error(rt_group_last_error(grp));
+        }
+        std::vector<uint8_t> img_c(img_a.size());
+        RtContext* last = nullptr;
+        rt_group_context(grp, (int)ordinals.size() - 1, &last);  // any device holds the whole frame
+        if (rt_read_output_bgra8(last, img_c.data()) != RT_OK) throw std::runtime_error(rt_last_error(last));
+        rt_group_destroy(grp);
         rt_scene_destroy(built);
+        if (img_c != img_b) {
+            std::printf("group of %zu device(s) in row strips: DIFFERENT from one device\n", ordinals.size());
+            return 1;
+        }
+        std::printf("group of %zu device(s) in row strips: identical to one device\n", ordinals.size());
 
         size_t lit = 0;
         for (size_t i = 0; i < img_a.size(); i += 4) lit += (img_a[i] | img_a[i + 1] | img_a[i + 2]) != 0;

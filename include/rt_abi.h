@@ -181,6 +181,7 @@ typedef struct RtStats {
 } RtStats;
 
 typedef struct RtContext RtContext;
+typedef struct RtScene RtScene;   /* host scene, see "host scene surface" below */
 
 /* ------------------------------------------------------------------ device path */
 
@@ -284,9 +285,57 @@ const char* rt_last_error(RtContext* ctx); /* ctx may be NULL: error of the last
 void rt_default_params(RtParams* out);     /* spp 5, max_bounces 20, BVH, all rows, no flags     */
 int  rt_abi_version(void);
 
+/* ------------------------------------------------------------------ several GPUs of one node
+ * The reference renders on one GPU; these entry points have no counterpart in it beyond the per-frame
+ * call they multiply, drawFrame (main.cpp:1308-1392).  A pixel depends only on (x, y, time, frameCount)
+ * and the read-only scene (raytracer.comp:959-961), and frames couple only through the additive
+ * accumulation (990-992), so the work divides two ways with the scene replicated on every GPU:
+ *   row strips - one frame's rows dealt to the GPUs in strips of strip_rows rows (RtParams.strip_*),
+ *                completed everywhere by ONE all-gather of each GPU's packed rows; same bits as one GPU;
+ *   samples    - whole frames (distinct frameCount, hence distinct random streams) dealt to the GPUs,
+ *                each accumulating privately; one reduction (sum) of colours and counts per batch.   */
+
+/* Bytes of one context's packed rows under a strip partition (the same for every strip_index: room for
+ * the largest share, rounded up to 16): owned rows in ascending y, all float4 colours first, then all
+ * int32 counts. */
+size_t rt_strip_staging_bytes(int32_t width, int32_t height, int32_t strip_rows, int32_t strip_count);
+/* Copy the context's own rows (accumulated colours + counts) into d_staging (device memory, 16-byte
+ * aligned, rt_strip_staging_bytes).  Asynchronous on the context's stream. */
+int rt_strip_pack(RtContext* ctx, int32_t strip_rows, int32_t strip_count, int32_t strip_index, void* d_staging);
+/* d_gathered = the packed rows of strip_count contexts back to back (what an all-gather of the staging
+ * buffers yields): write every context's rows except skip_index's (-1: none) into this context's
+ * framebuffer and rebuild their BGRA8 bytes.  Asynchronous on the context's stream. */
+int rt_strip_unpack(RtContext* ctx, int32_t strip_rows, int32_t strip_count, int32_t skip_index, const void* d_gathered);
+
+/* One host thread driving n devices: a context per device plus an RCCL communicator over them
+ * (single process, ncclCommInitAll; librccl.so is loaded here, on first use). */
+typedef struct RtGroup RtGroup;
+enum { RT_GROUP_STRIPS = 0, RT_GROUP_SAMPLES = 1 };
+int rt_group_create(int n_devices, const int* device_ordinals, RtGroup** out); /* failure text: rt_last_error(NULL) */
+int rt_group_destroy(RtGroup* grp);
+int rt_group_size(const RtGroup* grp);
+int rt_group_context(RtGroup* grp, int index, RtContext** out);  /* borrowed: e.g. for rt_read_*, rt_get_stats */
+int rt_group_upload_scene_from(RtGroup* grp, const RtScene* s);  /* replicated on every device */
+int rt_group_resize(RtGroup* grp, int32_t width, int32_t height);
+/* RT_GROUP_STRIPS: one reference frame, rendered by all devices in strips of strip_rows rows and
+ * completed on every device (all-gather over xGMI); afterwards each context holds the whole frame, bit
+ * for bit what rt_render_frame gives on one device.  params->strip_* are overwritten.
+ * RT_GROUP_SAMPLES: n frames at once - device i renders frameCount + i into its own accumulator
+ * (strip_rows ignored); combine them with rt_group_reduce_samples when the batch is complete.
+ * Asynchronous on the contexts' streams. */
+int rt_group_render_frame(RtGroup* grp, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params,
+                          int mode, int32_t strip_rows);
+/* Sum of all devices' accumulated colours and counts on device 0 (one ncclReduce each) and its BGRA8 image
+ * in context 0's output; the devices' own accumulators are left as they are, so a progressive
+ * rendering can go on and be reduced again.  Float sums run in the reduction's order, not in frame
+ * order: equal to sequential accumulation within rounding, not bit for bit (one device: bit for bit). */
+int rt_group_reduce_samples(RtGroup* grp);
+int rt_group_read_total(RtGroup* grp, float* accum_float4, int32_t* counts); /* the reduced buffers */
+int rt_group_sync(RtGroup* grp);
+const char* rt_group_last_error(RtGroup* grp);
+
 /* ------------------------------------------------------------------ host scene surface
  * C access to the C++ Scene builder that mirrors src/scene.hpp:8-37 / src/scene.cpp. */
-typedef struct RtScene RtScene;
 
 enum { RT_SCENE_EMPTY = 0,
        RT_SCENE_CORNELL_STAR = 1,   /* Scene::createCornellBox verbatim (scene.cpp:350-695)    */

@@ -39,6 +39,7 @@ RT_FLAG_FIXED_TILE_ORDER = 128
 RT_MODEL_FULL_GLTF, RT_MODEL_REBASE_INDICES = 1, 2
 RT_SKY_GREY, RT_SKY_DAY, RT_SKY_NIGHT, RT_SKY_WHITE, RT_SKY_BLACK = 0, 1, 2, 3, 4
 RT_PIPELINE_SINGLE, RT_PIPELINE_POOLED = 0, 2
+RT_GROUP_STRIPS, RT_GROUP_SAMPLES = 0, 1
 RT_OPT_EXIT_QUOTA_PCT, RT_OPT_REFILL_MIN, RT_OPT_POOL_BURST, RT_OPT_POOL_JOB_MIN = 1, 2, 3, 4
 RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF = 5, 6, 7
 
@@ -149,6 +150,20 @@ PROTOTYPES = {
     "rt_render_frame_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), _P, _P, _P,
                                           C.c_int32, C.c_int32]),
     "rt_resolve": (C.c_int, [_P]),
+    "rt_strip_staging_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_strip_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "rt_strip_unpack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "rt_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "rt_group_destroy": (C.c_int, [_P]),
+    "rt_group_size": (C.c_int, [_P]),
+    "rt_group_context": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "rt_group_upload_scene_from": (C.c_int, [_P, _P]),
+    "rt_group_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "rt_group_render_frame": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), C.c_int, C.c_int32]),
+    "rt_group_reduce_samples": (C.c_int, [_P]),
+    "rt_group_read_total": (C.c_int, [_P, _P, _P]),
+    "rt_group_sync": (C.c_int, [_P]),
+    "rt_group_last_error": (C.c_char_p, [_P]),
     "rt_read_output_bgra8": (C.c_int, [_P, _P]),
     "rt_read_accum": (C.c_int, [_P, _P, _P]),
     "rt_read_debug": (C.c_int, [_P, _P, _P]),

@@ -74,6 +74,92 @@ class StripExchange:
                 buf.index_copy_(0, dst, recv.index_select(0, src))
 
 
+def staging_rows(height: int, strip_rows: int, world: int) -> int:
+    """Rows a rank's packed block has room for: rank 0's share, the largest."""
+    return int(strip_rows_of(height, strip_rows, world, 0).numel())
+
+
+def staging_bytes(height: int, width: int, strip_rows: int, world: int) -> int:
+    """rt_strip_staging_bytes: 20 bytes per pixel of the largest share, rounded up to 16."""
+    return (staging_rows(height, strip_rows, world) * width * 20 + 15) // 16 * 16
+
+
+def pack_rows_torch(acc: torch.Tensor, cnt: torch.Tensor, strip_rows: int, world: int, rank: int, out: torch.Tensor) -> None:
+    """The byte layout of rt_strip_pack, in torch (CPU rehearsals and as a check of the kernel): this
+    rank's rows in ascending y, all float4 colours first, then all int32 counts."""
+    height, width = cnt.shape
+    rows = strip_rows_of(height, strip_rows, world, rank).to(acc.device)
+    cap = staging_rows(height, strip_rows, world)
+    a = out[:cap * width * 16].view(torch.float32).view(cap, width, 4)
+    c = out[cap * width * 16:cap * width * 20].view(torch.int32).view(cap, width)
+    a[:rows.numel()] = acc.index_select(0, rows)
+    c[:rows.numel()] = cnt.index_select(0, rows)
+
+
+def resolve_torch(acc: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
+    """acc / max(1, count) as B,G,R,A bytes in one int32 per pixel (raytracer.comp:992-995; rgba8 store =
+    clamp, x 255, round to nearest even)."""
+    d = cnt.clamp(min=1).to(torch.float32).unsqueeze(-1)
+    q = torch.round(torch.nan_to_num(acc / d, nan=0.0).clamp(0.0, 1.0) * 255.0).to(torch.int32)
+    packed = q[..., 2] | (q[..., 1] << 8) | (q[..., 0] << 16) | (q[..., 3] << 24)
+    return packed.to(torch.int32)
+
+
+def unpack_rows_torch(gathered: torch.Tensor, acc: torch.Tensor, cnt: torch.Tensor, bgra: torch.Tensor, strip_rows: int,
+                      world: int, skip: int) -> None:
+    """rt_strip_unpack in torch: every rank's rows except `skip`'s into the frame, BGRA8 rebuilt."""
+    height, width = cnt.shape
+    cap = staging_rows(height, strip_rows, world)
+    per = staging_bytes(height, width, strip_rows, world)
+    for r in range(world):
+        if r == skip:
+            continue
+        rows = strip_rows_of(height, strip_rows, world, r).to(acc.device)
+        blk = gathered[r * per:(r + 1) * per]
+        a = blk[:cap * width * 16].view(torch.float32).view(cap, width, 4)[:rows.numel()]
+        c = blk[cap * width * 16:cap * width * 20].view(torch.int32).view(cap, width)[:rows.numel()]
+        acc.index_copy_(0, rows, a)
+        cnt.index_copy_(0, rows, c)
+        bgra.index_copy_(0, rows, resolve_torch(a, c))
+
+
+class PackedStripExchange:
+    """The strip exchange with ONE all-gather per frame: each rank packs its rows' colours and counts into
+    one staging buffer (20 bytes per pixel; the BGRA8 bytes are not sent but rebuilt from colours and
+    counts on arrival), the staging buffers are gathered, and every other rank's rows are unpacked.
+    With a Context (`ctx`) the packing and unpacking are the library's kernels on its stream
+    (rt_strip_pack / rt_strip_unpack on the framebuffer bound to it); without one they are the torch
+    restatements above (CPU rehearsals with gloo)."""
+
+    def __init__(self, acc: torch.Tensor, cnt: torch.Tensor, bgra: torch.Tensor, strip_rows: int, world: int, rank: int,
+                 ctx=None, group: Optional[dist.ProcessGroup] = None, include_self: bool = False):
+        self.acc, self.cnt, self.bgra = acc, cnt, bgra
+        self.strip_rows, self.world, self.rank, self.ctx, self.group = strip_rows, world, rank, ctx, group
+        self.skip = -1 if include_self else rank
+        height, width = cnt.shape
+        self.bytes = staging_bytes(height, width, strip_rows, world)
+        self.send = torch.zeros(self.bytes, dtype=torch.uint8, device=acc.device)
+        self.recv = torch.empty(self.bytes * world, dtype=torch.uint8, device=acc.device)
+
+    def pack(self) -> None:
+        """Own rows -> staging (on the context's stream when there is one)."""
+        if self.ctx is not None:
+            self.ctx.strip_pack(self.strip_rows, self.world, self.rank, self.send.data_ptr())
+        else:
+            pack_rows_torch(self.acc, self.cnt, self.strip_rows, self.world, self.rank, self.send)
+
+    def gather(self) -> None:
+        """The one collective (torch's current stream)."""
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+
+    def unpack(self) -> None:
+        """Other ranks' rows -> frame, BGRA8 rebuilt (on the context's stream when there is one)."""
+        if self.ctx is not None:
+            self.ctx.strip_unpack(self.strip_rows, self.world, self.skip, self.recv.data_ptr())
+        else:
+            unpack_rows_torch(self.recv, self.acc, self.cnt, self.bgra, self.strip_rows, self.world, self.skip)
+
+
 _EXCHANGES: dict = {}
 
 

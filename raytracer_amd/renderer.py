@@ -272,6 +272,14 @@ class Context:
                                                     C.c_void_p(accum_ptr), C.c_void_p(counts_ptr), C.c_void_p(bgra_ptr),
                                                     int(width), int(height)), "rt_render_frame_noalloc")
 
+    def strip_pack(self, strip_rows: int, strip_count: int, strip_index: int, staging_ptr: int):
+        self._chk(self._lib.rt_strip_pack(self._h, int(strip_rows), int(strip_count), int(strip_index), C.c_void_p(staging_ptr)),
+                  "rt_strip_pack")
+
+    def strip_unpack(self, strip_rows: int, strip_count: int, skip_index: int, gathered_ptr: int):
+        self._chk(self._lib.rt_strip_unpack(self._h, int(strip_rows), int(strip_count), int(skip_index), C.c_void_p(gathered_ptr)),
+                  "rt_strip_unpack")
+
     def resolve(self):
         self._chk(self._lib.rt_resolve(self._h), "rt_resolve")
 
@@ -318,3 +326,67 @@ class Context:
     @property
     def stream(self) -> int:
         return int(self._lib.rt_get_stream(self._h) or 0)
+
+
+class Group:
+    """n devices driven from one host thread (rt_group_*): a context per device and an RCCL communicator."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.rt_group_create(len(devices), arr, C.byref(self._h))
+        if rc != capi.RT_OK:
+            raise RtError(rc, "rt_group_create", (self._lib.rt_last_error(None) or b"").decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc != capi.RT_OK:
+            raise RtError(rc, where, (self._lib.rt_group_last_error(self._h) or b"").decode())
+
+    def __len__(self):
+        return int(self._lib.rt_group_size(self._h))
+
+    def context(self, index: int) -> "Context":
+        """A borrowed view of device `index`'s context (do not close it)."""
+        h = C.c_void_p()
+        self._chk(self._lib.rt_group_context(self._h, int(index), C.byref(h)), "rt_group_context")
+        c = Context.__new__(Context)
+        c._lib, c._h, c.width, c.height = self._lib, h, self.width, self.height
+        c.close = lambda: None
+        return c
+
+    def upload_scene(self, scene: Scene):
+        self._chk(self._lib.rt_group_upload_scene_from(self._h, scene.handle), "rt_group_upload_scene_from")
+
+    def resize(self, width: int, height: int):
+        self._chk(self._lib.rt_group_resize(self._h, int(width), int(height)), "rt_group_resize")
+        self.width, self.height = int(width), int(height)
+
+    def render_frame(self, camera, pc, params, mode: int, strip_rows: int = 0):
+        self._chk(self._lib.rt_group_render_frame(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None,
+                                                  int(mode), int(strip_rows)), "rt_group_render_frame")
+
+    def reduce_samples(self):
+        self._chk(self._lib.rt_group_reduce_samples(self._h), "rt_group_reduce_samples")
+
+    def read_total(self):
+        acc = np.empty((self.height, self.width, 4), dtype=np.float32)
+        cnt = np.empty((self.height, self.width), dtype=np.int32)
+        self._chk(self._lib.rt_group_read_total(self._h, acc.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)),
+                  "rt_group_read_total")
+        return acc, cnt
+
+    def sync(self):
+        self._chk(self._lib.rt_group_sync(self._h), "rt_group_sync")

@@ -1,0 +1,89 @@
+"""Several GPUs behind the C ABI, on the one GPU a test box has: the row-strip exchange kernels
+(rt_strip_pack / rt_strip_unpack) reassemble a frame rendered share by share into the bits of the
+whole frame, their byte layout is the one raytracer_amd.parallel restates in torch, and a group of one
+device (rt_group_*, RCCL communicator included) equals rt_render_frame bit for bit in both modes."""
+import numpy as np
+import pytest
+
+from helpers import bit_equal_pixels
+from raytracer_amd import capi
+from raytracer_amd.renderer import Context, Group, Scene, default_camera, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(ctx, scene, W, H, frames, strip=(0, 1, 0)):
+    for f in range(frames):
+        ctx.render_frame(default_camera(W, H), scene.push_constants(0.0, f, f == 0), make_params(2, 4, capi.RT_ACCEL_BVH, *strip))
+
+
+def test_strip_pack_and_unpack_rebuild_the_whole_frame():
+    import torch
+    from raytracer_amd import parallel
+    scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
+    ctx = Context(0)
+    try:
+        W, H, rows, world = 130, 37, 4, 3
+        ctx.upload_scene(scene)
+        ctx.resize(W, H)
+        _frames(ctx, scene, W, H, 2)
+        whole_acc, whole_cnt = ctx.read_accum()
+        whole_bgra = ctx.read_bgra8()
+        per = capi.load().rt_strip_staging_bytes(W, H, rows, world)
+        assert per == parallel.staging_bytes(H, W, rows, world) and per % 16 == 0
+        gathered = torch.zeros(per * world, dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            ctx.resize(W, H)  # zeroed: only this share's rows get written
+            _frames(ctx, scene, W, H, 2, strip=(rows, world, r))
+            ctx.strip_pack(rows, world, r, gathered.data_ptr() + r * per)
+            ctx.sync()
+            acc, cnt = ctx.read_accum()
+            mine = torch.zeros(per, dtype=torch.uint8)
+            parallel.pack_rows_torch(torch.from_numpy(acc), torch.from_numpy(cnt), rows, world, r, mine)
+            assert torch.equal(gathered[r * per:(r + 1) * per].cpu(), mine), f"packed bytes of share {r}"
+        ctx.resize(W, H)
+        ctx.strip_unpack(rows, world, -1, gathered.data_ptr())
+        acc, cnt = ctx.read_accum()
+        assert bit_equal_pixels(acc, whole_acc).all() and np.array_equal(cnt, whole_cnt)
+        assert np.array_equal(ctx.read_bgra8(), whole_bgra)
+        # skipping a share leaves its rows alone
+        ctx.resize(W, H)
+        ctx.strip_unpack(rows, world, 1, gathered.data_ptr())
+        _, cnt = ctx.read_accum()
+        skipped = [y for y in range(H) if (y // rows) % world == 1]
+        assert (cnt[skipped] == 0).all() and (np.delete(cnt, skipped, axis=0) == 2).all()
+    finally:
+        ctx.close()
+
+
+def test_group_of_one_device_equals_render_frame():
+    scene = Scene(capi.RT_SCENE_CORNELL_STAR)
+    W, H = 200, 117
+    ctx = Context(0)
+    try:
+        ctx.upload_scene(scene)
+        ctx.resize(W, H)
+        _frames(ctx, scene, W, H, 3)
+        want_acc, want_cnt = ctx.read_accum()
+        want_bgra = ctx.read_bgra8()
+    finally:
+        ctx.close()
+    g = Group([0])
+    try:
+        assert len(g) == 1
+        g.upload_scene(scene)
+        g.resize(W, H)
+        c0 = g.context(0)
+        for mode in (capi.RT_GROUP_STRIPS, capi.RT_GROUP_SAMPLES):
+            for f in range(3):
+                g.render_frame(default_camera(W, H), scene.push_constants(0.0, f, f == 0), make_params(2, 4, capi.RT_ACCEL_BVH), mode, 9)
+            if mode == capi.RT_GROUP_SAMPLES:
+                g.reduce_samples()
+                acc, cnt = g.read_total()
+                assert bit_equal_pixels(acc, want_acc).all() and np.array_equal(cnt, want_cnt)
+            g.sync()
+            acc, cnt = c0.read_accum()
+            assert bit_equal_pixels(acc, want_acc).all() and np.array_equal(cnt, want_cnt), mode
+            assert np.array_equal(c0.read_bgra8(), want_bgra), mode
+    finally:
+        g.close()

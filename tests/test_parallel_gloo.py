@@ -27,13 +27,19 @@ def _worker(rank, world, port, mode, outdir):
     s = Scene(capi.RT_SCENE_CORNELL_STAR)
     cam = default_camera(W, H)
     osc = ob.OracleScene(s.arrays())
-    if mode == "strips":
+    if mode in ("strips", "packed"):
         out = ob.render(osc, cam, s.push_constants(0.0, 0, True), W, H, SPP, MB, threads=2, strip=(STRIP, world, rank))
         acc = torch.from_numpy(out["accum"])
         cnt = torch.from_numpy(out["counts"])
         bgra = torch.from_numpy(out["bgra"].view(np.int32).reshape(H, W).copy())
-        parallel.gather_strips([acc, cnt, bgra], H, STRIP, world, rank)
-        np.savez(os.path.join(outdir, f"strips_{rank}.npz"), accum=acc.numpy(), counts=cnt.numpy(), bgra=bgra.numpy())
+        if mode == "strips":
+            parallel.gather_strips([acc, cnt, bgra], H, STRIP, world, rank)
+        else:  # one all-gather of packed colours + counts; the BGRA8 bytes of the other rank's rows are rebuilt
+            ex = parallel.PackedStripExchange(acc, cnt, bgra, STRIP, world, rank)
+            ex.pack()
+            ex.gather()
+            ex.unpack()
+        np.savez(os.path.join(outdir, f"{mode}_{rank}.npz"), accum=acc.numpy(), counts=cnt.numpy(), bgra=bgra.numpy())
     else:
         acc_np = np.zeros((H, W, 4), np.float32)
         cnt_np = np.zeros((H, W), np.int32)
@@ -49,15 +55,16 @@ def _run(mode, tmp_path, port):
     mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
 
 
-def test_row_strips_two_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("mode,port", [("strips", 29611), ("packed", 29613)])
+def test_row_strips_two_ranks_equal_one_rank(tmp_path, mode, port):
     sys.path.insert(0, HERE)
     from helpers import bit_equal_pixels, oracle_frames
     from raytracer_amd import capi
     from raytracer_amd.renderer import Scene
-    _run("strips", tmp_path, 29611)
+    _run(mode, tmp_path, port)
     whole = oracle_frames(Scene(capi.RT_SCENE_CORNELL_STAR), W, H, SPP, MB, threads=2)
     for r in range(2):
-        got = np.load(tmp_path / f"strips_{r}.npz")
+        got = np.load(tmp_path / f"{mode}_{r}.npz")
         assert bit_equal_pixels(got["accum"], whole["accum"]).all()  # identical bits: global pixel coordinates seed the RNG
         assert np.array_equal(got["counts"], whole["counts"])
         assert np.array_equal(got["bgra"].view(np.uint8).reshape(H, W, 4), whole["bgra"])
