@@ -178,6 +178,9 @@ typedef struct RtStats {
                                     result, light-query result, sample end); cycles_search then
                                     holds the search section, cycles_shade the sum of the four and
                                     cycles_raygen everything else (queue polls, waiting, start)  */
+    uint64_t busy_lane_iterations; /* pooled pipeline with TRAVERSAL_STATS: lanes that held a ray, summed over
+                                      the search steps of all waves (lane_iterations counts those that took the
+                                      step: the rest waited for the other kind of step)                      */
 } RtStats;
 
 typedef struct RtContext RtContext;

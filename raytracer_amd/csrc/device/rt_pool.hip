@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     trav_reset(tv, kTravDone);
     float t_occl = -kInf;  // a light query ends at the first hit nearer than this
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, guard = 0;
-    unsigned long long wave_iters = 0;
+    unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
     unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0;  // STATS: wave cycles
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 const unsigned long long m_node = __ballot(tv.cur >= 0 && tv.cur != kTravDone);
                 const unsigned long long m_leaf = __ballot(tv.cur < 0);
                 if ((m_node | m_leaf) == 0ull) break;
-                if (STATS) wave_iters++;
+                if (STATS) { wave_iters++; busy_iters += (unsigned long long)__popcll(m_node | m_leaf); }
                 if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
                     if (tv.cur >= 0 && tv.cur != kTravDone) {
                         const int sp_before = tv.sp;
@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);
             atomicAdd((unsigned long long*)(fa.counters + 16), nn + (ACCEL == 1 ? nt : 0ull));
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
+            atomicAdd((unsigned long long*)(fa.counters + 40), busy_iters);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), job_stats[k]);
             atomicAdd((unsigned long long*)(fa.counters + 28), (dp4 << 40) | (dp6 << 20) | dp8);
             const unsigned long long shade_cycles = job_cycles[0] + job_cycles[1] + job_cycles[2] + job_cycles[3];
