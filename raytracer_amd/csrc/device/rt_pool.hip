@@ -13,7 +13,7 @@
 // stage a 1080p frame has too few rays per launch to fill this chip.
 // Here a workgroup keeps kPool paths in flight for its lanes.  Slots that wait for the
 // same kind of work queue up in LDS (search, first-bounce result, later-bounce result,
-// light-query result, sample end); a wave either
+// sample end); a wave either
 //   * shades: pops 64 slots of ONE kind and runs that stage for all of them, or
 //   * searches: its lanes walk the BVH for 64 rays, and a lane whose ray has ended stores
 //     the result, queues the slot for its stage and pops the next waiting ray.
@@ -50,7 +50,7 @@ constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
 constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
-enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_LIGHT = 3, Q_END = 4, kQueues = 5 };
+enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, kQueues = 4 };
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -63,6 +63,7 @@ struct PoolLds {
     uint32_t phash[kPool];
     float hit_t[kPool];
     int32_t hit_idx[kPool];
+    uint32_t flags[(kPool + 3) / 4];  // one byte per slot: LF_* of the sample's light query (changed by LDS atomics on the word)
     // queues
     uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
     // What every wave polls once per round, in one 32-byte block (two 16-byte LDS reads):
@@ -73,11 +74,11 @@ struct PoolLds {
     alignas(16) uint32_t hc[kQueues];
     uint32_t live;
     uint32_t abort;
-    uint32_t ctl_pad;
+    uint32_t ctl_pad[2];
     uint32_t tail[kQueues];          // next ring position to push
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
-static_assert(kQueues == 5 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
+static_assert(kQueues == 4 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
 static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing, "a queue entry is a 12-bit slot index plus a kind, and a ring holds every slot");
 static_assert(kThreads % 64 == 0 && kThreads <= 1024, "whole waves, one workgroup");
 
@@ -87,8 +88,8 @@ struct PoolCtl {
     uint32_t count[kQueues], live, abort;
 };
 
-// Accessor of slot i: hot fields in LDS, cold record (pixel sum, pixel cost | normal, light distance |
-// incoming direction, packed light / material / face bits; 64-byte stride) in device memory.
+// Accessor of slot i: hot fields in LDS, cold record (pixel sum, pixel cost | the light's term: normal,
+// light distance | incoming direction, packed bits | light direction, hit id; 64 bytes) in device memory.
 struct PoolSlot {
     PoolLds& L;
     float4* cold;
@@ -114,21 +115,28 @@ struct PoolSlot {
     RT_DEV FrameArgs late_frame(const FrameArgs&) const { return kernarg_frame(); }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
-    // bounds of a light query's search, kept in the hit fields until the search overwrites them
-    RT_DEV void put_search_bounds(float t_max, float t_occl) const { L.hit_t[i] = t_max; L.hit_idx[i] = __float_as_int(t_occl); }
-    RT_DEV void put_light_query(const LightQuery& q) const {
-        // 32 bytes: normal, light distance | incoming direction, front face << 31 | light << 16 | material
-        // (the host offers this kernel only to scenes with at most 32768 lights and 65536 materials)
+    RT_DEV void put_hash(uint32_t phash) const { L.phash[i] = phash; }
+    // What the light's term of the sample needs at its end (LightRecord), 44 bytes of the cold record:
+    // normal, light distance | incoming direction, front face << 31 | light << 16 | material | light
+    // direction, the query's hit id (hash mode).  (The host offers this kernel only to scenes with at most
+    // 32768 lights and 65536 materials.)
+    RT_DEV void put_light_record(const LightRecord& q) const {
         cold[1] = f4(q.normal, q.s_d);
         cold[2] = f4(q.vdir, __uint_as_float((q.front_face ? 0x80000000u : 0u) | ((uint32_t)q.light << 16) | (uint32_t)q.mat));
+        cold[3] = f4(q.ldir, 0.0f);
     }
-    RT_DEV void get_light_query(LightQuery& q) const {
-        const float4 n = cold[1], v = cold[2];
+    RT_DEV void get_light_record(LightRecord& q) const {
+        const float4 n = cold[1], v = cold[2], l = cold[3];
         const uint32_t bits = __float_as_uint(v.w);
         q.normal = xyz(n); q.s_d = n.w;
         q.vdir = xyz(v); q.light = (int)((bits >> 16) & 0x7fffu);
         q.mat = (int)(bits & 0xffffu); q.front_face = (bits >> 31) != 0u;
+        q.ldir = xyz(l);
     }
+    RT_DEV int get_light_hit_id() const { return __float_as_int(cold[3].w); }  // written when the per-pixel hash is on
+    RT_DEV uint32_t get_flags() const { return (*(const volatile __attribute__((address_space(3))) uint32_t*)&L.flags[i >> 2] >> (8u * (i & 3u))) & 0xffu; }
+    RT_DEV void put_flags(uint32_t f) const { *(volatile __attribute__((address_space(3))) uint8_t*)((uint8_t*)L.flags + i) = (uint8_t)f; }
+    RT_DEV uint32_t or_flags(uint32_t bits) const { return (atomicOr(&L.flags[i >> 2], bits << (8u * (i & 3u))) >> (8u * (i & 3u))) & 0xffu; }
 };
 
 // Volatile accesses to the workgroup's LDS block go through LDS-typed pointers (a volatile
@@ -143,9 +151,8 @@ RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     const u32x4 b = *(const volatile lds_u32x4*)&L.hc[4];
     PoolCtl c;
     c.count[0] = a.x & 0xffffu; c.count[1] = a.y & 0xffffu; c.count[2] = a.z & 0xffffu; c.count[3] = a.w & 0xffffu;
-    c.count[4] = b.x & 0xffffu;
-    c.live = b.y;
-    c.abort = b.z;
+    c.live = b.x;
+    c.abort = b.y;
     return c;
 }
 
@@ -302,7 +309,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     // only its share of slots (the rest stay dead), so that all CUs get work.
     const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
     const uint32_t per_wave = share >= (uint32_t)kPool ? (uint32_t)(kPool / kWaves) : (share + kWaves - 1u) / kWaves;
-    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
         const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
@@ -316,7 +323,10 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     Slab sl = make_slab(ro, rd);
     Trav tv;
     trav_reset(tv, kTravDone);
-    float t_occl = -kInf;  // a light query ends at the first hit nearer than this
+    float s_d = -kInf;     // a light query's distance to the sampled light point (+inf: directional light; -inf: a path ray)
+    const bool hash_mode = (fa.flags & 2u) != 0u;
+    const float occl_bias = hash_mode ? kInf : 0.2f;
+    bool search_first = false;  // skip the look for shading work once
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, guard = 0;
     unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
@@ -329,11 +339,9 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (ctl.abort != 0u) break;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
-        const uint32_t c_first = ctl.count[Q_FIRST], c_next = ctl.count[Q_NEXT];
-        const uint32_t c_light = ctl.count[Q_LIGHT], c_end = ctl.count[Q_END];
-        int q = Q_LIGHT;
-        uint32_t best = c_light;
-        if (c_next > best) { best = c_next; q = Q_NEXT; }
+        const uint32_t c_first = ctl.count[Q_FIRST], c_next = ctl.count[Q_NEXT], c_end = ctl.count[Q_END];
+        int q = Q_NEXT;
+        uint32_t best = c_next;
         if (c_first > best) { best = c_first; q = Q_FIRST; }
         if (c_end > best) { best = c_end; q = Q_END; }
         const unsigned long long busy = __ballot(slot >= 0);
@@ -342,54 +350,74 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         // pixels than slots) a sixteenth of the live paths must do, or they would wait for each other
         uint32_t job_thresh = ctl.live >> 4;
         job_thresh = job_thresh < 1u ? 1u : (job_thresh > (uint32_t)job_min ? (uint32_t)job_min : job_thresh);
-        if (best >= job_thresh || (nothing_to_search && best != 0u)) {
+        if (!search_first && (best >= job_thresh || (nothing_to_search && best != 0u))) {
             uint32_t item = 0;
             bool got;
             const unsigned long long t_job = STATS ? __builtin_readcyclecounter() : 0ull;
             const uint32_t n_items = queue_pop(L, q, ~0ull, best >= job_thresh ? job_thresh : 1u, item, got);
             if (n_items == 0u) continue;
             guard = 0;
-            if (STATS) job_stats[q - Q_FIRST] += ((unsigned long long)n_items << 32) | 1ull;
+            const int jk = q == Q_END ? 3 : q - Q_FIRST;  // STATS index: first-bounce, later-bounce, (unused), sample end
+            if (STATS) job_stats[jk] += ((unsigned long long)n_items << 32) | 1ull;
             const uint32_t i = item & 0xfffu;
             const PoolSlot ps{L, cold_base + 4 * i, i};
             if (q == Q_END) {
                 bool alive = false;
-                if (got) end_item(fa, ps, alive);
+                if (got) end_item(sc, fa, ps, alive);
                 const bool started = take_pixels(L, fa, cold_base, got && !alive, i);
-                queue_push(L, Q_SEARCH, (got && alive) || started, i);  // WF_PATH_FIRST: next sample or next pixel
+                queue_push(L, Q_SEARCH, (got && alive) || started, i);  // kind 0: next sample or next pixel
             } else {
-                bool ends = false;
-                uint32_t next_stage = WF_IDLE;
-                if (got) ends = shade_item(sc, fa, ps, recs, q - Q_FIRST, WF_LIGHT_SEARCH + (item >> 12), next_stage);
-                // where the slot goes next: sample end, search (path ray or light query, the kind in the
-                // entry), or straight to the light-result stage when the light needs no search
+                bool ends = false, retry = false;
+                int light_kind = 0;
+                if (got) ends = shade_item(sc, fa, ps, recs, q - Q_FIRST, light_kind, retry);
+                // a first hit may send a light query on its way beside the path
+                if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12));
+                // the path: its next ray, or its end - where the sample waits for its light query if that is still
+                // out (whoever of the two comes last queues the sample's end)
                 int to = -1;
                 uint32_t entry = i;
-                if (got && ends) {
-                    to = Q_END;
-                } else if (got && next_stage == WF_PATH_NEXT) {
+                if (got && retry) {
+                    to = Q_NEXT;
+                } else if (got && !ends) {
                     to = Q_SEARCH; entry = i | (1u << 12);
-                } else if (got && next_stage == WF_LIGHT_SEARCH) {
-                    to = Q_SEARCH; entry = i | (2u << 12);
-                } else if (got && next_stage >= WF_LIGHT_AMBIENT && next_stage <= WF_LIGHT_UNDEF) {
-                    to = Q_LIGHT; entry = i | ((next_stage - WF_LIGHT_SEARCH) << 12);
+                } else if (got) {
+                    bool last = true;
+                    if (ps.get_flags() & LF_PENDING) last = (ps.or_flags(LF_PATH_DONE) & LF_DONE) != 0u;
+                    if (last) to = Q_END;
                 }
                 queue_push_any(L, to, entry);
+                // items put back (per-pixel hash only: they wait for their light query's hit id) must not keep
+                // the waves from the searching that would end the wait
+                search_first = __ballot(got && retry) != 0ull;
             }
-            if (STATS) job_cycles[q - Q_FIRST] += __builtin_readcyclecounter() - t_job;
+            if (STATS) job_cycles[jk] += __builtin_readcyclecounter() - t_job;
             continue;
         }
+        search_first = false;
 
         // ---- search: retire the lanes whose ray has ended, hand them the next waiting rays
         const unsigned long long t_search = STATS ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long ended = __ballot(tv.cur == kTravDone && slot >= 0);
         if (ended != 0ull) {
             const bool mine = (tv.cur == kTravDone && slot >= 0);
-            if (mine) {
+            int to = -1;
+            if (mine && skind < 2) {  // a path ray: its hit goes to the stage of its kind
                 L.hit_t[slot] = tv.best_t;
                 L.hit_idx[slot] = tv.best_idx;
+                to = Q_FIRST + skind;
             }
-            queue_push_any(L, mine ? Q_FIRST + skind : -1, (uint32_t)slot);  // Q_FIRST / Q_NEXT / Q_LIGHT (entry kind bits 0 = searched)
+            if (hash_mode && mine && skind >= 2)  // the query's hit id, for the per-pixel hash
+                ((int*)(cold_base + 4 * slot + 3))[3] = tv.best_idx >= 0 ? __float_as_int(recs[3 * tv.best_idx].w) : -1;
+            if (hash_mode) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (mine && skind >= 2) {
+                // a light query: the light is visible if the nearest hit lies within 0.1 of the sampled point
+                // (raytracer.comp:617-626, 662-671), a directional one if nothing is hit (636-644).  The
+                // sample's end is queued by whichever of query and path finishes last.
+                const bool visible = skind == 3 ? tv.best_idx < 0 : (tv.best_idx >= 0 && g_abs(s_d - tv.best_t) < 0.1f);
+                const PoolSlot ps{L, cold_base + 4 * slot, (uint32_t)slot};
+                if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = Q_END;
+            }
+            queue_push_any(L, to, (uint32_t)slot);
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
@@ -399,17 +427,32 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             if (queue_pop(L, Q_SEARCH, idle, 1u, item, got) != 0u && got) {
                 slot = (int)(item & 0xfffu);
                 skind = (int)(item >> 12);
-                ro = v3(L.ro[0][slot], L.ro[1][slot], L.ro[2][slot]);
-                rd = v3(L.rd[0][slot], L.rd[1][slot], L.rd[2][slot]);
+                {
+                    ro = v3(L.ro[0][slot], L.ro[1][slot], L.ro[2][slot]);
+                    rd = v3(L.rd[0][slot], L.rd[1][slot], L.rd[2][slot]);
+                    s_d = -kInf;
+                }
+                if (skind >= 2) {
+                    // a light query: from the shading point (the slot's ro) along the vector to the sampled light
+                    // point, which its first hit left in the slot's sample radiance; distance and direction are
+                    // the length and the normalisation the shader takes of it (raytracer.comp:612-614, 657-659),
+                    // a directional light's direction is used as it is (635)
+                    const V3 to_light = v3(L.col[0][slot], L.col[1][slot], L.col[2][slot]);
+                    s_d = skind == 3 ? kInf : length(to_light);
+                    rd = skind == 3 ? to_light : normalize(to_light);
+                    L.col[0][slot] = 0.0f; L.col[1][slot] = 0.0f; L.col[2][slot] = 0.0f;  // the sample's radiance again
+                    (void)PoolSlot{L, cold_base + 4 * slot, (uint32_t)slot}.or_flags(LF_FETCHED);
+                }
                 n_rays++;
                 if (ACCEL == 1) {
                     sl = make_slab(ro, rd);
                     trav_reset(tv, 0);  // node 0 is always an internal node
-                    t_occl = -kInf;
-                    if (skind == 2) {
-                        tv.best_t = L.hit_t[slot];
-                        t_occl = __int_as_float(L.hit_idx[slot]);
-                    }
+                    // A light query only asks whether the nearest hit lies within 0.1 of the sampled point's
+                    // distance s_d, or, for a directional light, whether anything is hit at all: its search is
+                    // bounded to t < s_d + 0.2 and ends at the first hit nearer than s_d - 0.2 (any hit for a
+                    // directional light).  Not when the per-pixel hash of nearest-hit ids is recorded, which
+                    // needs the true nearest hit (occl_bias is infinite then).
+                    if (skind == 2) tv.best_t = s_d + occl_bias;
                 } else {
                     trav_reset(tv, kTravDone);
                     trace_flat(sc, ro, rd, tv.best_t, tv.best_idx);
@@ -440,7 +483,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 } else {
                     if (tv.cur < 0) {
                         trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
-                        if (tv.best_t < t_occl) tv.cur = kTravDone;
+                        if (tv.best_t < s_d - occl_bias) tv.cur = kTravDone;  // a light query is settled (never true for path rays)
                         if (STATS) n_tests++;
                     }
                 }

@@ -11,129 +11,119 @@ RT_DEV unsigned long long lanes_below() { return (1ull << lane_id()) - 1ull; }
 RT_DEV V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
 RT_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
-// What a slot keeps across a light query besides the query ray itself (whose origin is the
-// shading point): normal, material and facing of the shading point, the direction of the
-// path ray that reached it, the distance to the sampled light point and the light's index.
-struct LightQuery {
-    V3 normal;
-    V3 vdir;
-    int mat;
-    bool front_face;
-    float s_d;
-    int light;
+// A sample's light query (raytracer.comp:907-910 -> 870-881 -> 582-679) runs BESIDE its path: every
+// random draw of sample_light and of sample_mat happens before either of the two searches that follow a
+// first-bounce hit, and the query's only product is one term of the sample's radiance.  So the stage
+// that handles the first hit picks the light, notes what the term needs, sends off the visibility ray
+// and the bounce ray together, and the sample's end evaluates the term if the light proved visible.
+// Per-slot flag bits:
+enum : uint32_t {
+    LF_PENDING = 1u,   // this sample has a light query in flight or finished
+    LF_DONE = 2u,      // its search has ended
+    LF_LIT = 4u,       // ... and the light is visible from the shading point
+    LF_PATH_DONE = 8u, // the path has ended; the sample waits for the query only
+    LF_FOLDED = 16u,   // (per-pixel hash only) the query's hit id has been folded into the hash
+    LF_FETCHED = 32u   // a lane has taken the query's ray (which sits in slot fields the path will reuse)
 };
 
-// A path result (kind 0: bounce 0, kind 1: later bounces; raytracer.comp:891-921) or a
-// light-query result (kind 2, `stage` = which of the WF_LIGHT_* cases; raytracer.comp:617-671,
-// 870-881), followed for the lanes that reach it by the bounce itself: sample_mat + eval_mat
-// (raytracer.comp:913-921).  Returns true when the sample ends here (end_item follows);
-// otherwise next_stage is what the slot waits for now.
+// What the light's term needs at the sample's end: the shading point's normal, material and facing, the
+// direction of the path ray that reached it, the direction and distance of the sampled light point and the
+// light's index.
+struct LightRecord {
+    V3 normal, vdir, ldir;
+    float s_d;
+    int mat, light;
+    bool front_face;
+};
+
+// A path result: `kind` 0 = the hit of a sample's first ray (bounce 0), 1 = of a later one
+// (raytracer.comp:891-921), followed for the lanes that reach it by the bounce itself: sample_mat +
+// eval_mat (913-921).  Returns true when the PATH ends here.  Otherwise the slot's next path ray is in
+// its ro / rd.  light_kind: 0 = no light query to send, 2 = a visibility ray towards a sampled point,
+// 3 = towards a directional light; its origin is the slot's ro (the bounce starts there too), the vector
+// to the light point sits in the slot's sample radiance (unused until the path adds to it).
+// `retry`: the item cannot be handled yet and must be queued again - its sample's light query has not been
+// taken by a lane yet (its ray would be overwritten), or, in hash mode, has not reported its hit id.
 template <typename Slot>
 RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& sl, const float4* __restrict__ recs, int kind,
-                       uint32_t stage, uint32_t& next_stage) {
+                       int& light_kind, bool& retry) {
     uint32_t seed, pixel, sample, phash;
     int bounce;
+    light_kind = 0;
+    retry = false;
+    const bool hash_mode = (fa.flags & 2u) != 0u;
+    if (kind == 1) {
+        const uint32_t f = sl.get_flags();
+        if (f & LF_PENDING) {
+            if (!(f & LF_FETCHED)) { retry = true; return false; }
+            if (hash_mode && !(f & LF_FOLDED)) {
+                // the reference folds ids in program order: primary hit, light query hit, later hits
+                if (!(f & LF_DONE)) { retry = true; return false; }
+                (void)sl.get_att(phash);
+                sl.put_hash((phash ^ (uint32_t)(sl.get_light_hit_id() + 1)) * 0x01000193u);
+                sl.or_flags(LF_FOLDED);
+            }
+        }
+    }
     sl.get_ctl(seed, pixel, sample, bounce);
     V3 att = sl.get_att(phash);
     bool do_bsdf = false, to_end = false;
-    next_stage = WF_IDLE;
     Hit h;
     h.p = v3(0.0f); h.normal = v3(0.0f); h.mat = 0; h.t = 0.0f; h.front_face = false;
-    V3 V = v3(0.0f);
     Material mat;
-
-    if (kind == 2) {
-        LightQuery q;
-        sl.get_light_query(q);
-        h.p = sl.get_ro();
-        const V3 s_L = sl.get_rd();
-        h.mat = q.mat;
-        h.front_face = q.front_face;
-        h.normal = q.normal;
-        V = -q.vdir;
-        const float4 lc = sc.lights[3 * q.light + 1];
-        const int ltype = __float_as_int(sc.lights[3 * q.light + 2].x);
-        V3 Le = v3(0.0f), Ldir = v3(0.0f);
-        float light_pdf = 0.0f;
-        if (stage == WF_LIGHT_SEARCH) {
-            float hit_t;
-            int hit_idx;
-            sl.get_hit(hit_t, hit_idx);
-            const int prim_id = (hit_idx >= 0) ? __float_as_int(recs[3 * hit_idx].w) : -1;
-            phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
-            light_arrival(ltype, lc, hit_idx, hit_t, q.s_d, s_L, h.normal, Le, Ldir, light_pdf);
-        } else if (stage == WF_LIGHT_AMBIENT) {
-            Ldir = s_L;
-            light_pdf = 1.0f / 2.0f / kPi;
-            Le = v3(lc.x, lc.y, lc.z);
-        } else if (stage == WF_LIGHT_UNDEF) {
-            Le = v3(1.0f);
-        }
-        mat = load_material(sc.materials, h.mat);
-        if (Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f) {
-            // the first thing a sample adds to its radiance (raytracer.comp:907-910)
-            sl.put_col(v3(0.0f) + direct_term(mat, h, V, Le, Ldir, light_pdf, att));
-        }
-        do_bsdf = true;
+    const V3 ro = sl.get_ro();
+    const V3 rd = sl.get_rd();
+    float hit_t;
+    int hit_idx;
+    sl.get_hit(hit_t, hit_idx);
+    int prim_id = -1;
+    uint32_t flags = 0;  // kind 0: the new sample's flags
+    if (hit_idx < 0) {
+        sl.put_col(sl.get_col() + att * skybox_color(fa.skybox, rd));  // raytracer.comp:575-577, 924
+        to_end = true;
     } else {
-        const V3 ro = sl.get_ro();
-        const V3 rd = sl.get_rd();
-        float hit_t;
-        int hit_idx;
-        sl.get_hit(hit_t, hit_idx);
-        int prim_id = -1;
-        if (hit_idx < 0) {
-            sl.put_col(sl.get_col() + att * skybox_color(fa.skybox, rd));  // raytracer.comp:575-577, 924
+        make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);
+        mat = load_material(sc.materials, h.mat);
+        if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
+            sl.put_ro(h.p);
+            bounce++;
+            if (bounce > fa.max_bounces) to_end = true;
+        } else if (mat.emission_a > 0.0f) {  // raytracer.comp:901-904
+            sl.put_col(sl.get_col() + att * mat.emission);
             to_end = true;
         } else {
-            make_hit(sc, recs, hit_idx, hit_t, ro, rd, h, prim_id);
-            mat = load_material(sc.materials, h.mat);
-            if (mat.albedo_a < 1.0f && mat.albedo_a < rng_random(seed)) {  // raytracer.comp:895-898
-                sl.put_ro(h.p);
-                bounce++;
-                if (bounce > fa.max_bounces) to_end = true; else next_stage = WF_PATH_NEXT;
-            } else if (mat.emission_a > 0.0f) {  // raytracer.comp:901-904
-                sl.put_col(sl.get_col() + att * mat.emission);
-                to_end = true;
-            } else if (kind == 0 && !(fa.total_lights == 0 || fa.lights_strength_sum <= 0.0f)) {
-                LightQuery q;
-                V3 s_L;
-                const int k = light_pick(sc, fa, h, seed, q.light, s_L, q.s_d);
-                q.normal = h.normal;
-                q.vdir = rd;
-                q.mat = h.mat;
-                q.front_face = h.front_face;
-                sl.put_light_query(q);
-                sl.put_ro(h.p);
-                sl.put_rd(s_L);
-                if (k == 0) {
-                    // A light-visibility query only asks whether the nearest hit lies within 0.1 of the
-                    // sampled point's distance s_d (raytracer.comp:617-626, 662-671), or, for a directional
-                    // light, whether anything is hit at all (636-644): its search may be bounded to
-                    // t < s_d + 0.2 and end at the first hit nearer than s_d - 0.2.  Not when the per-pixel
-                    // hash of nearest-hit ids is recorded, which needs the true nearest hit.
-                    float t_max = kInf, t_occl = -kInf;
-                    if (!(fa.flags & 2u)) {
-                        if (__float_as_int(sc.lights[3 * q.light + 2].x) == 3 /* DIRECTIONAL */) {
-                            t_occl = kInf;
-                        } else {
-                            t_max = q.s_d + 0.2f;
-                            t_occl = q.s_d - 0.2f;
-                        }
+            if (kind == 0 && !(fa.total_lights == 0 || fa.lights_strength_sum <= 0.0f)) {
+                // direct_light (raytracer.comp:870-881), first half: pick and sample the light (582-616,
+                // 633-635, 653-661)
+                LightRecord q;
+                V3 to_light;
+                const int k = light_pick(sc, fa, h, seed, q.light, q.ldir, q.s_d, to_light);
+                if (k != 2) {  // k == 2: a directional light below the horizon, nothing arrives
+                    q.normal = h.normal;
+                    q.vdir = rd;
+                    q.mat = h.mat;
+                    q.front_face = h.front_face;
+                    sl.put_light_record(q);
+                    if (k == 0) {  // visibility to be searched
+                        sl.put_col(to_light);  // the query's ray, until a lane has taken it
+                        light_kind = (__float_as_int(sc.lights[3 * q.light + 2].x) == 3 /* DIRECTIONAL */) ? 3 : 2;
+                        flags = LF_PENDING;
+                    } else {  // no search: AMBIENT (not shadow-tested) and the shader's undefined light types count as lit
+                        flags = LF_PENDING | LF_FETCHED | LF_DONE | LF_LIT | LF_FOLDED;
                     }
-                    sl.put_search_bounds(t_max, t_occl);
                 }
-                next_stage = WF_LIGHT_SEARCH + (uint32_t)k;
-            } else {
-                V = -rd;
-                do_bsdf = true;
             }
+            do_bsdf = true;
         }
-        if (kind == 0 && sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel] = prim_id;
-        phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
     }
+    if (kind == 0) {
+        sl.put_flags(flags);
+        if (sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel] = prim_id;
+    }
+    phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
     if (do_bsdf) {
+        const V3 V = -rd;
         V3 bounce_dir = sample_mat(mat, V, h, seed);
         float mat_pdf;
         V3 fr = eval_mat(mat, bounce_dir, V, h, mat_pdf);
@@ -142,11 +132,43 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
         sl.put_ro(h.p);
         sl.put_rd(bounce_dir);
         bounce++;
-        if (bounce > fa.max_bounces) to_end = true; else next_stage = WF_PATH_NEXT;
+        if (bounce > fa.max_bounces) to_end = true;
     }
     sl.put_ctl(seed, pixel, sample, bounce);
     sl.put_att(att, phash);
     return to_end;
+}
+
+// The light's term of a sample whose light proved visible or needs no search (raytracer.comp:602-606, 617-626,
+// 636-644, 662-671, then 870-881), evaluated from the record its first hit left: the sample's radiance after the term.
+template <typename Slot>
+RT_DEV V3 lit_term(const DeviceScene& sc, const Slot& sl) {
+    LightRecord q;
+    sl.get_light_record(q);
+    Hit h;
+    h.p = v3(0.0f); h.t = 0.0f;
+    h.normal = q.normal; h.mat = q.mat; h.front_face = q.front_face;
+    const float4 lc = sc.lights[3 * q.light + 1];
+    const int ltype = __float_as_int(sc.lights[3 * q.light + 2].x);
+    V3 Le;
+    float light_pdf;
+    if (ltype == 3 /* DIRECTIONAL */) {
+        light_pdf = 1.0f;
+        Le = v3(lc.x, lc.y, lc.z);
+    } else if (ltype == 0 /* AMBIENT */) {
+        light_pdf = 1.0f / 2.0f / kPi;
+        Le = v3(lc.x, lc.y, lc.z);
+    } else if (ltype == 1 /* SPHERE */ || ltype == 6 /* TRIANGLE */) {
+        light_pdf = (ltype == 1) ? (1.0f / 2.0f / kPi) : 1.0f;
+        Le = g_clamp(v3(lc.x, lc.y, lc.z) * lc.w / (q.s_d * q.s_d), 0.0f, 1.0f);
+    } else {  // POINT / CONE / AREA fall through the shader's switch: vec3(1) with L and pdf never written (zero here)
+        light_pdf = 0.0f;
+        Le = v3(1.0f);
+    }
+    // with no emission arriving the term is +0 whatever the BSDF says
+    if (!(Le.x != 0.0f || Le.y != 0.0f || Le.z != 0.0f)) return v3(0.0f);
+    const Material mat = load_material(sc.materials, q.mat);
+    return v3(0.0f) + direct_term(mat, h, -q.vdir, Le, q.ldir, light_pdf, v3(1.0f));  // the attenuation at bounce 0 is 1
 }
 
 // First primary ray of a sample (get_ray, raytracer.comp:933-952) into the slot.
@@ -165,15 +187,21 @@ RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uin
 // End of a sample (raytracer.comp:925/929, 974) and either the next sample's primary ray or
 // the pixel's gamma, accumulation and rgba8 store (raytracer.comp:978-995).
 template <typename Slot>
-RT_DEV void end_item(const FrameArgs& fa, const Slot& sl, bool& alive) {
+RT_DEV void end_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& sl, bool& alive) {
     uint32_t seed, pixel, sample, phash;
     int bounce;
     sl.get_ctl(seed, pixel, sample, bounce);
     sample += 1u;
     float cost;  // path segments of the pixel so far (a small integer, exact in binary32)
-    V3 pix = sl.get_pix(cost) + g_clamp(sl.get_col(), 0.0f, 1.0f);
+    // the sample's radiance: what the light query found (added first, as the shader does at bounce 0:
+    // raytracer.comp:907-910) plus what the path collected
+    const uint32_t lf = sl.get_flags();
+    V3 col = sl.get_col();
+    if (lf & LF_LIT) col = lit_term(sc, sl) + col;
+    V3 pix = sl.get_pix(cost) + g_clamp(col, 0.0f, 1.0f);
     cost += (float)(bounce + 1);
     (void)sl.get_att(phash);
+    if ((fa.flags & 2u) && (lf & LF_PENDING) && !(lf & LF_FOLDED)) phash = (phash ^ (uint32_t)(sl.get_light_hit_id() + 1)) * 0x01000193u;
     if ((int)sample < fa.spp) {
         sl.put_pix(pix, cost);
         start_sample(fa, sl, seed, pixel, sample, phash);

@@ -341,7 +341,10 @@ RT_DEV V3 direct_term(const Material& mat, const Hit& h, V3 V, V3 Le, V3 Ldir, f
 //   0 = visibility search along s_L (distance s_d), 1 = no search, arrival known (AMBIENT:
 //   Ldir in s_L), 2 = no search, nothing arrives (DIRECTIONAL facing away), 3 = no search,
 //   the shader's undefined light types (Le = 1, L = 0, pdf = 0).
-RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, uint32_t& seed, int& light, V3& s_L, float& s_d) {
+//   `to_light` receives the vector s_L and s_d derive from (s_d = length, s_L = normalize of it; for a
+//   directional light s_L itself).
+RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, uint32_t& seed, int& light, V3& s_L, float& s_d,
+                      V3& to_light) {
     float rand_strength = rng_random(seed) * fa.lights_strength_sum;
     int low = 0, high = fa.total_lights - 1;
     while (low < high) {
@@ -353,6 +356,7 @@ RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, 
     const int ltype = __float_as_int(sc.lights[3 * low + 2].x);
     s_d = 0.0f;
     s_L = v3(0.0f);
+    to_light = v3(0.0f);
     if (ltype == 0 /* AMBIENT */) {
         s_L = random_vec_on_hemisphere(h.normal, seed);
         return 1;
@@ -364,12 +368,14 @@ RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, 
         V3 pts = sphere_point - h.p;
         s_d = length(pts);
         s_L = normalize(pts);
+        to_light = pts;
         return 0;
     }
     if (ltype == 3 /* DIRECTIONAL */) {
         V3 light_dir = -v3(lp.x, lp.y, lp.z);
         if (dot(h.normal, light_dir) > 0.0f) {
             s_L = light_dir;
+            to_light = light_dir;
             return 0;
         }
         return 2;
@@ -385,6 +391,7 @@ RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, 
         V3 pts = tri_point - h.p;
         s_d = length(pts);
         s_L = normalize(pts);
+        to_light = pts;
         return 0;
     }
     // POINT / CONE / AREA fall through the shader's switch (raytracer.comp:628-651) and
