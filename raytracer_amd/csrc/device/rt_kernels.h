@@ -100,7 +100,7 @@ int pool_threads_per_block();
 // per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid)
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, int job_min, hipStream_t stream);
+                       int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 // Turns the per-tile costs of the frame just rendered into the next frame's tile order (most
 // expensive class first, image order within a class) and clears the costs.  At most

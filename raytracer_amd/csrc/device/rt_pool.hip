@@ -293,7 +293,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
 
 template <int ACCEL, bool STATS>
 __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
-                                                         int burst, int job_min) {
+                                                         int burst, int job_min, int slots_cap) {
     __shared__ PoolLds L;
     extern __shared__ uint32_t s_stack[];  // [kShortStack][kThreads]
     const int tid = (int)threadIdx.x;
@@ -307,8 +307,10 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     if (tid < kQueues) { L.hc[tid] = 0; L.tail[tid] = 0; }
     // A frame with fewer pixels than the pools have slots is shared out evenly: every workgroup fills
     // only its share of slots (the rest stay dead), so that all CUs get work.
+    // `slots_cap` (a multiple of the waves, at most kPool) limits the paths in flight further: a scene that
+    // overflows the caches runs faster with fewer rays competing for them.
     const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
-    const uint32_t per_wave = share >= (uint32_t)kPool ? (uint32_t)(kPool / kWaves) : (share + kWaves - 1u) / kWaves;
+    const uint32_t per_wave = share >= (uint32_t)slots_cap ? (uint32_t)slots_cap / (uint32_t)kWaves : (share + kWaves - 1u) / kWaves;
     if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
@@ -524,7 +526,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     }
 }
 
-typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int);
+typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int);
 PoolKernel pick_kernel(int accel, bool stats) {
     return accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
 }
@@ -552,9 +554,10 @@ hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, i
 }
 
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, int job_min, hipStream_t stream) {
+                       int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(pick_kernel(accel, stats), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min);
+    slots_cap = (slots_cap <= 0 || slots_cap > kPool) ? kPool : (slots_cap < kWaves ? kWaves : slots_cap / kWaves * kWaves);
+    hipLaunchKernelGGL(pick_kernel(accel, stats), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap);
     return hipGetLastError();
 }
 

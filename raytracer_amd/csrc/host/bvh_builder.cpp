@@ -417,6 +417,46 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_lea
     return true;
 }
 
+// Re-lays the nodes out in treelets: a subtree's top `levels` levels (up to 2^levels - 1 nodes) back to
+// back, breadth first, then the same for each subtree hanging below, in order.  levels <= 1 keeps the
+// builder's depth-first order.  The root stays node 0; only positions and child indices change.
+void layout_treelets(HostBvh& bvh, int levels) {
+    if (levels <= 1 || bvh.nodes.size() < 3) return;
+    const std::vector<BvhNode>& old = bvh.nodes;
+    std::vector<int32_t> new_index(old.size(), -1);
+    std::vector<int32_t> order;  // order[new] = old
+    order.reserve(old.size());
+    std::vector<int32_t> roots = {0};  // treelet roots still to emit (a stack: subtrees stay contiguous)
+    std::vector<int32_t> level, next;
+    while (!roots.empty()) {
+        const int32_t root = roots.back();
+        roots.pop_back();
+        level.assign(1, root);
+        std::vector<int32_t> frontier;
+        for (int d = 0; d < levels && !level.empty(); ++d) {
+            next.clear();
+            for (int32_t n : level) {
+                new_index[(size_t)n] = (int32_t)order.size();
+                order.push_back(n);
+                const BvhNode& nd = old[(size_t)n];
+                if (nd.count0 == 0 && nd.child0 >= 0) next.push_back(nd.child0);
+                if (nd.count1 == 0 && nd.child1 >= 0) next.push_back(nd.child1);
+            }
+            level.swap(next);
+        }
+        // what hangs below the treelet, first child's subtree emitted first
+        for (size_t k = level.size(); k-- > 0;) roots.push_back(level[k]);
+    }
+    std::vector<BvhNode> out(old.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        BvhNode nd = old[(size_t)order[k]];
+        if (nd.count0 == 0 && nd.child0 >= 0) nd.child0 = new_index[(size_t)nd.child0];
+        if (nd.count1 == 0 && nd.child1 >= 0) nd.child1 = new_index[(size_t)nd.child1];
+        out[k] = nd;
+    }
+    bvh.nodes.swap(out);
+}
+
 bool validate_bvh(const HostBvh& bvh, std::string* err) {
     if (bvh.nodes.empty()) return fail(err, "no root node");
     std::vector<int> node_seen(bvh.nodes.size(), 0), prim_seen(bvh.prims.size(), 0);

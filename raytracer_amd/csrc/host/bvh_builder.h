@@ -68,6 +68,10 @@ static const int kMaxBvhDepth = 30;  // traversal stacks hold kMaxBvhDepth + 2 e
 // max_leaf: most primitives per leaf, 1..8 (anything else: 4).
 bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_leaf = 4);
 
+// Re-lays the nodes out in treelets of `levels` levels (breadth first inside a treelet, treelets depth
+// first); levels <= 1 keeps the builder's depth-first order.  Same tree, same traversal, other addresses.
+void layout_treelets(HostBvh& bvh, int levels);
+
 // Structural self-check: every node reachable exactly once, every primitive in exactly one
 // leaf, every leaf box contains its primitives, every stored child box contains the boxes
 // stored below it, depth and leaf size within the traversal kernel's limits.

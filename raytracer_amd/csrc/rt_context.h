@@ -15,9 +15,11 @@ struct RtOptions {
     int refill_min = 16;      // pooled kernel: idle lanes of a searching wave before it fetches new rays
     int pool_burst = 16;      // pooled kernel: search steps between two looks at the queues
     int pool_job_min = 64;    // pooled kernel: queue entries that make a shading job
+    int pool_slots = 0;       // pooled kernel: paths in flight per workgroup (0: the library's choice by scene size)
     int tile_classes = 16;    // cost classes of the frame-to-frame tile order
     int pool_per_cu = 0;      // pooled kernel: cap on workgroups per CU (0: what fits)
     int bvh_max_leaf = 4;     // builder: most primitives per leaf (takes effect at the next rt_upload_scene)
+    int bvh_treelet = 0;      // node layout: levels per treelet (0 / 1: depth-first order; next rt_upload_scene)
 };
 
 struct RtContext {
