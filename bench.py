@@ -31,28 +31,38 @@ from raytracer_amd.workloads import WORKLOADS, workload_camera  # noqa: E402
 FRAMES_PER_BATCH = 16  # sample sharding: frames per progressive batch (c4: 16 x 4 spp = 64 spp)
 STRIP_ROWS = 9  # 1080 / 9 = 120 strips: divisible by 1, 2, 4 and 8 ranks
 
-# MI355X vector FP32 peak (spec): 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
-PEAK_VALU_TFLOPS = 157.3
+# MI355X vector FP32 peaks (spec): 256 CU x 4 SIMD x 2.4 GHz x 16 lanes x 2 flop (FMA) = 78.6 TFLOP/s for the
+# one-result-per-lane instructions this build uses (-fno-slp-vectorize: packed v_pk_*_f32 issue no faster here
+# and cost register shuffles); 157.3 TFLOP/s with packed FMA (two results per lane).
+PEAK_VALU_TFLOPS_PACKED = 157.3
+PEAK_VALU_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0
 
 
-def cpu_baseline(scene: Scene, max_bounces: int) -> dict:
-    """The CPU oracle (flat search = the reference's algorithm) on a bounded sample of the
-    same scene and camera: 1280x720 pixels, 2 spp (about 15 s on the GPU box's 16-core share)."""
+def cpu_baseline() -> dict:
+    """The CPU oracle (flat search = the reference's algorithm: every ray against every primitive) on
+    BASELINE.json's CPU-runnable configuration C1 in full: Cornell box + teapot.glb, 640x360, 1 spp,
+    primary + 1 bounce, canonical camera, time 0, frame 0 (a few seconds on the GPU box's 16-core share;
+    median of three frames)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    w, h, spp = 1280, 720, 2
+    preset, w, h, spp, mb, desc = WORKLOADS["c1"]
+    scene = Scene(preset)
     threads = max(1, min(16, os.cpu_count() or 1))
-    cam = default_camera(w, h)
+    cam = workload_camera("c1", w, h)
     osc = ob.OracleScene(scene.arrays())
     pc = scene.push_constants(0.0, 0, True)
-    t0 = time.perf_counter()
-    out = ob.render(osc, cam, pc, w, h, spp, max_bounces, threads=threads, want_debug=False)
-    dt = time.perf_counter() - t0
-    return {"value": out["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"same scene and camera at {w}x{h}, {spp} spp, {max_bounces} bounces, flat search "
-                      f"(every ray x every primitive, as the reference shader), {out['rays']} rays in {dt:.2f} s"}
+    times, rays = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = ob.render(osc, cam, pc, w, h, spp, mb, threads=threads, want_debug=False)
+        times.append(time.perf_counter() - t0)
+        rays = out["rays"]
+    dt = sorted(times)[1]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "ms_per_frame": dt * 1e3,
+            "sample": f"c1: {desc}; flat search (every ray x every primitive, as the reference shader), "
+                      f"{rays} rays per frame, median of 3 frames {dt * 1e3:.0f} ms"}
 
 
 def main() -> None:
@@ -227,15 +237,26 @@ def main() -> None:
         achieved_tflops = launch_flops / (avg_kernel_ms * 1e-3) / 1e12
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_passes.sh) of
         # this workload on one GPU; bench.py cannot run the profiler on itself.
-        traffic, traffic_note, issue = None, None, {}
+        traffic, traffic_note, issue, executed = None, None, {}, {}
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"{args.workload}:{pipeline}")
             if rec and world == 1 and args.accel == "bvh":
                 traffic = (rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024.0
-                traffic_note = rec["note"]
-                # from the same passes: share of the SIMDs' time with a vector instruction in flight (about 1 =
-                # the vector pipes are saturated) and the share of lanes active in those instructions
-                issue = {k: rec[k] for k in ("valu_active_frac", "lane_utilisation", "l2_hit") if k in rec}
+                traffic_note = rec["note"] + " [" + rec["source"] + "]"
+                # from the same passes: share of the SIMDs' vector issue slots used (an instruction holds its SIMD's port
+                # for 4 clocks), share of the SIMDs' time with a vector instruction in flight, share of lanes active in
+                # those instructions, L2 hit rate, L1 / texture-address path busy, wave cycles waiting on memory
+                issue = {k: rec[k] for k in ("valu_issue_frac", "valu_active_frac", "lane_utilisation", "l2_hit", "ta_busy", "wait_frac") if k in rec}
+                fp = rec.get("fp32_wave_insts")
+                if fp:
+                    # FP32 arithmetic the kernel ISSUED (counted by the hardware per wave instruction, x 64 lanes, fma = 2),
+                    # and what is left of it after the nearest-hit search's algorithmic flops: shading (BSDF evaluation and
+                    # sampling, light sampling, hit records, ray generation, gamma), plus lanes masked off in either part
+                    issued = (fp["add"] + fp["mul"] + 2.0 * fp["fma"] + fp["trans"]) * 64.0
+                    executed = {"issued_fp32_flops_per_launch": issued,
+                                "issued_fp32_flops_per_ray": issued / max(1.0, rays_per_launch),
+                                "shading_and_masked_flops_per_ray": issued / max(1.0, rays_per_launch) - flops_per_ray,
+                                "transcendental_wave_insts_per_launch": fp["trans"]}
         except (OSError, ValueError, KeyError):
             pass
         result = {
@@ -263,8 +284,11 @@ def main() -> None:
                 "kernel": {"single": "render_kernel", "pooled": "pool_kernel"}[pipeline],
                 "achieved": achieved_tflops,
                 "peak": PEAK_VALU_TFLOPS,
+                "peak_note": "vector FP32 with one result per lane (what this build issues); with packed FMA the peak is "
+                             f"{PEAK_VALU_TFLOPS_PACKED} TFLOP/s (frac_packed)",
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_VALU_TFLOPS,
+                "frac_packed": achieved_tflops / PEAK_VALU_TFLOPS_PACKED,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "avg_kernel_ms": avg_kernel_ms,
@@ -275,10 +299,11 @@ def main() -> None:
                 "algorithmic_GBps": launch_bytes / (avg_kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
                 **issue,
+                **executed,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene, max_bounces)
+            result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
 
     ctx.close()

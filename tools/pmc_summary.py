@@ -49,3 +49,9 @@ if have("TCC_HIT_sum", "TCC_REQ_sum"):
     print(f"# L2 hit rate                         {m['TCC_HIT_sum'] / m['TCC_REQ_sum']:.3f}")
 if have("TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"):
     print(f"# L1 hit rate                         {1.0 - m['TCP_TCC_READ_REQ_sum'] / m['TCP_TOTAL_CACHE_ACCESSES_sum']:.3f}")
+if have("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+    # every vector instruction occupies its SIMD's issue port for 4 clocks (a 64-wide wave on 16 lanes)
+    print(f"# VALU issue slots used               {m['SQ_INSTS_VALU'] * 4.0 / (1024.0 * m['GRBM_GUI_ACTIVE'] / 8.0):.3f}")
+if have("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"):
+    a, mu, f, t = (m[k] for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"))
+    print(f"# FP32 wave instructions              add {a:.4g} mul {mu:.4g} fma {f:.4g} transcendental {t:.4g}  (x 64 lanes, fma = 2 flop: {(a + mu + 2 * f + t) * 64 / 1e9:.1f} Gflop issued per launch)")
