@@ -181,6 +181,8 @@ typedef struct RtStats {
     uint64_t busy_lane_iterations; /* pooled pipeline with TRAVERSAL_STATS: lanes that held a ray, summed over
                                       the search steps of all waves (lane_iterations counts those that took the
                                       step: the rest waited for the other kind of step)                      */
+    uint64_t cycles_steps;  /* pooled pipeline with TRAVERSAL_STATS: the part of cycles_search spent in the bursts of
+                               search steps (the rest: handing results in, taking new rays)                      */
 } RtStats;
 
 typedef struct RtContext RtContext;

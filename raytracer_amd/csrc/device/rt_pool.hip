@@ -12,8 +12,8 @@
 // next, and most vector instructions run with most lanes masked off; with one launch per
 // stage a 1080p frame has too few rays per launch to fill this chip.
 // Here a workgroup keeps kPool paths in flight for its lanes.  Slots that wait for the
-// same kind of work queue up in LDS (search, first-bounce result, later-bounce result,
-// sample end); a wave either
+// same kind of work queue up in LDS (search, first-bounce result, later-bounce result, the
+// light's term, sample end, pixel end); a wave either
 //   * shades: pops 64 slots of ONE kind and runs that stage for all of them, or
 //   * searches: its lanes walk the BVH for 64 rays, and a lane whose ray has ended stores
 //     the result, queues the slot for its stage and pops the next waiting ray.
@@ -50,7 +50,7 @@ constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
 constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
-enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, kQueues = 4 };
+enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, Q_LIT = 4, Q_PIXEL = 5, kQueues = 6 };
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -74,11 +74,10 @@ struct PoolLds {
     alignas(16) uint32_t hc[kQueues];
     uint32_t live;
     uint32_t abort;
-    uint32_t ctl_pad[2];
     uint32_t tail[kQueues];          // next ring position to push
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
-static_assert(kQueues == 4 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
+static_assert(kQueues == 6 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
 static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing, "a queue entry is a 12-bit slot index plus a kind, and a ring holds every slot");
 static_assert(kThreads % 64 == 0 && kThreads <= 1024, "whole waves, one workgroup");
 
@@ -151,8 +150,9 @@ RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     const u32x4 b = *(const volatile lds_u32x4*)&L.hc[4];
     PoolCtl c;
     c.count[0] = a.x & 0xffffu; c.count[1] = a.y & 0xffffu; c.count[2] = a.z & 0xffffu; c.count[3] = a.w & 0xffffu;
-    c.live = b.x;
-    c.abort = b.y;
+    c.count[4] = b.x & 0xffffu; c.count[5] = b.y & 0xffffu;
+    c.live = b.z;
+    c.abort = b.w;
     return c;
 }
 
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     // overflows the caches runs faster with fewer rays competing for them.
     const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
     const uint32_t per_wave = share >= (uint32_t)slots_cap ? (uint32_t)slots_cap / (uint32_t)kWaves : (share + kWaves - 1u) / kWaves;
-    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
         const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
@@ -329,11 +329,19 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const bool hash_mode = (fa.flags & 2u) != 0u;
     const float occl_bias = hash_mode ? kInf : 0.2f;
     bool search_first = false;  // skip the look for shading work once
+    // Where a sample goes when path and light query have both ended: to the light's term if the light is
+    // visible (`flags` as they were when the later of the two ended), else to the pixel's end after its last
+    // sample, else to the next sample.
+    const uint32_t last_sample = (uint32_t)kernarg_frame().spp - 1u;
+    auto end_queue = [&](const PoolSlot& ps, uint32_t flags) -> int {
+        if (flags & LF_LIT) return Q_LIT;
+        return (L.cnt[ps.i] >> 16) >= last_sample ? Q_PIXEL : Q_END;
+    };
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, guard = 0;
     unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
-    unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0;  // STATS: wave cycles
+    unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0, step_cycles = 0;  // STATS: wave cycles (step_cycles: the part of search_cycles inside the burst of steps)
     const unsigned long long t_begin = STATS ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
@@ -341,11 +349,12 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (ctl.abort != 0u) break;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
-        const uint32_t c_first = ctl.count[Q_FIRST], c_next = ctl.count[Q_NEXT], c_end = ctl.count[Q_END];
         int q = Q_NEXT;
-        uint32_t best = c_next;
-        if (c_first > best) { best = c_first; q = Q_FIRST; }
-        if (c_end > best) { best = c_end; q = Q_END; }
+        uint32_t best = ctl.count[Q_NEXT];
+        if (ctl.count[Q_FIRST] > best) { best = ctl.count[Q_FIRST]; q = Q_FIRST; }
+        if (ctl.count[Q_END] > best) { best = ctl.count[Q_END]; q = Q_END; }
+        if (ctl.count[Q_LIT] > best) { best = ctl.count[Q_LIT]; q = Q_LIT; }
+        if (ctl.count[Q_PIXEL] > best) { best = ctl.count[Q_PIXEL]; q = Q_PIXEL; }
         const unsigned long long busy = __ballot(slot >= 0);
         const bool nothing_to_search = (busy == 0ull) && ctl.count[Q_SEARCH] == 0u;
         // a job is worth a wave when it is full; when the pool runs thin (end of the frame, or fewer
@@ -359,15 +368,20 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             const uint32_t n_items = queue_pop(L, q, ~0ull, best >= job_thresh ? job_thresh : 1u, item, got);
             if (n_items == 0u) continue;
             guard = 0;
-            const int jk = q == Q_END ? 3 : q - Q_FIRST;  // STATS index: first-bounce, later-bounce, (unused), sample end
+            const int jk = q == Q_FIRST ? 0 : q == Q_NEXT ? 1 : q == Q_LIT ? 2 : 3;  // STATS index: first-bounce, later-bounce, light's term, sample / pixel end
             if (STATS) job_stats[jk] += ((unsigned long long)n_items << 32) | 1ull;
             const uint32_t i = item & 0xfffu;
             const PoolSlot ps{L, cold_base + 4 * i, i};
-            if (q == Q_END) {
-                bool alive = false;
-                if (got) end_item(sc, fa, ps, alive);
-                const bool started = take_pixels(L, fa, cold_base, got && !alive, i);
-                queue_push(L, Q_SEARCH, (got && alive) || started, i);  // kind 0: next sample or next pixel
+            if (q == Q_PIXEL) {
+                if (got) end_pixel_item(fa, ps);
+                const bool started = take_pixels(L, fa, cold_base, got, i);
+                queue_push(L, Q_SEARCH, started, i);  // kind 0: the next pixel's first ray
+            } else if (q == Q_END) {
+                if (got) end_sample_item(fa, ps);
+                queue_push(L, Q_SEARCH, got, i);  // kind 0: the next sample's first ray
+            } else if (q == Q_LIT) {
+                if (got) lit_item(sc, ps);
+                queue_push_any(L, got ? end_queue(ps, 0u) : -1, i);
             } else {
                 bool ends = false, retry = false;
                 int light_kind = 0;
@@ -383,13 +397,14 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 } else if (got && !ends) {
                     to = Q_SEARCH; entry = i | (1u << 12);
                 } else if (got) {
+                    uint32_t f = ps.get_flags();
                     bool last = true;
-                    if (ps.get_flags() & LF_PENDING) last = (ps.or_flags(LF_PATH_DONE) & LF_DONE) != 0u;
-                    if (last) to = Q_END;
+                    if (f & LF_PENDING) { f = ps.or_flags(LF_PATH_DONE); last = (f & LF_DONE) != 0u; }
+                    if (last) to = end_queue(ps, f);
                 }
                 queue_push_any(L, to, entry);
-                // items put back (per-pixel hash only: they wait for their light query's hit id) must not keep
-                // the waves from the searching that would end the wait
+                // items put back (they wait for their light query to be taken by a lane or, with the per-pixel hash,
+                // to report its hit id) must not keep the waves from the searching that would end the wait
                 search_first = __ballot(got && retry) != 0ull;
             }
             if (STATS) job_cycles[jk] += __builtin_readcyclecounter() - t_job;
@@ -417,7 +432,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 // sample's end is queued by whichever of query and path finishes last.
                 const bool visible = skind == 3 ? tv.best_idx < 0 : (tv.best_idx >= 0 && g_abs(s_d - tv.best_t) < 0.1f);
                 const PoolSlot ps{L, cold_base + 4 * slot, (uint32_t)slot};
-                if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = Q_END;
+                if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = end_queue(ps, visible ? LF_LIT : 0u);
             }
             queue_push_any(L, to, (uint32_t)slot);
             if (mine) slot = -1;
@@ -469,6 +484,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             continue;
         }
         guard = 0;
+        const unsigned long long t_steps = STATS ? __builtin_readcyclecounter() : 0ull;
         if (ACCEL == 1) {
             for (int it = 0; it < burst; ++it) {
                 const unsigned long long m_node = __ballot(tv.cur >= 0 && tv.cur != kTravDone);
@@ -491,7 +507,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 }
             }
         }
-        if (STATS) search_cycles += __builtin_readcyclecounter() - t_search;
+        if (STATS) { const unsigned long long now = __builtin_readcyclecounter(); search_cycles += now - t_search; step_cycles += now - t_steps; }
     }
 
     // ---- counters: one atomic per wave
@@ -519,6 +535,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             const unsigned long long shade_cycles = job_cycles[0] + job_cycles[1] + job_cycles[2] + job_cycles[3];
             atomicAdd((unsigned long long*)(fa.counters + 10), __builtin_readcyclecounter() - t_begin - shade_cycles - search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 12), search_cycles);
+            atomicAdd((unsigned long long*)(fa.counters + 42), step_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }

@@ -184,47 +184,64 @@ RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uin
     sl.put_col(v3(0.0f));
 }
 
-// End of a sample (raytracer.comp:925/929, 974) and either the next sample's primary ray or
-// the pixel's gamma, accumulation and rgba8 store (raytracer.comp:978-995).
+// The three things a sample's end may consist of are separate stages, so that each runs with full waves: the
+// light's term (only for samples whose light proved visible), the next sample's primary ray (15 of 16 ends at 16
+// spp), the pixel's end (the last sample's).
+
+// The light's term joins the sample's radiance: added first, as the shader does at bounce 0 (raytracer.comp:907-910).
 template <typename Slot>
-RT_DEV void end_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& sl, bool& alive) {
+RT_DEV void lit_item(const DeviceScene& sc, const Slot& sl) {
+    sl.put_col(lit_term(sc, sl) + sl.get_col());
+}
+
+// Sum of the pixel's samples so far with the one that just ended (raytracer.comp:925/929, 974); folds the light
+// query's hit id into the per-pixel hash if no later bounce did.
+template <typename Slot>
+RT_DEV V3 end_of_sample(const FrameArgs& fa, const Slot& sl, int bounce, float& cost, uint32_t& phash) {
+    const uint32_t lf = sl.get_flags();
+    V3 pix = sl.get_pix(cost) + g_clamp(sl.get_col(), 0.0f, 1.0f);
+    cost += (float)(bounce + 1);  // path segments of the pixel so far (a small integer, exact in binary32)
+    (void)sl.get_att(phash);
+    if ((fa.flags & 2u) && (lf & LF_PENDING) && !(lf & LF_FOLDED)) phash = (phash ^ (uint32_t)(sl.get_light_hit_id() + 1)) * 0x01000193u;
+    return pix;
+}
+
+// A sample that is not the pixel's last ends: the next sample's primary ray (raytracer.comp:972-975).
+template <typename Slot>
+RT_DEV void end_sample_item(const FrameArgs& fa, const Slot& sl) {
     uint32_t seed, pixel, sample, phash;
     int bounce;
     sl.get_ctl(seed, pixel, sample, bounce);
-    sample += 1u;
-    float cost;  // path segments of the pixel so far (a small integer, exact in binary32)
-    // the sample's radiance: what the light query found (added first, as the shader does at bounce 0:
-    // raytracer.comp:907-910) plus what the path collected
-    const uint32_t lf = sl.get_flags();
-    V3 col = sl.get_col();
-    if (lf & LF_LIT) col = lit_term(sc, sl) + col;
-    V3 pix = sl.get_pix(cost) + g_clamp(col, 0.0f, 1.0f);
-    cost += (float)(bounce + 1);
-    (void)sl.get_att(phash);
-    if ((fa.flags & 2u) && (lf & LF_PENDING) && !(lf & LF_FOLDED)) phash = (phash ^ (uint32_t)(sl.get_light_hit_id() + 1)) * 0x01000193u;
-    if ((int)sample < fa.spp) {
-        sl.put_pix(pix, cost);
-        start_sample(fa, sl, seed, pixel, sample, phash);
-        alive = true;
-    } else {
-        const auto& ff = sl.late_frame(fa);  // the frame's arguments, possibly loaded only here
-        V3 cc = g_pow(pix / (float)ff.spp, 1.0f / 2.2f);
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        int n = 0;
-        if (!ff.reset) {
-            a = ff.accum[pixel];
-            n = ff.counts[pixel];
-        }
-        a.x += cc.x; a.y += cc.y; a.z += cc.z; a.w += 1.0f;
-        n += 1;
-        ff.accum[pixel] = a;
-        ff.counts[pixel] = n;
-        ff.bgra[pixel] = resolve_pixel(a, n);
-        if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
-        const int py = (int)(pixel / (uint32_t)ff.width);
-        report_pixel_cost(ff, (int)pixel - py * ff.width, py, (uint32_t)cost);
-        alive = false;
+    float cost;
+    const V3 pix = end_of_sample(fa, sl, bounce, cost, phash);
+    sl.put_pix(pix, cost);
+    start_sample(fa, sl, seed, pixel, sample + 1u, phash);
+}
+
+// The pixel's last sample ends: gamma, accumulation and rgba8 store (raytracer.comp:978-995).
+template <typename Slot>
+RT_DEV void end_pixel_item(const FrameArgs& fa, const Slot& sl) {
+    uint32_t seed, pixel, sample, phash;
+    int bounce;
+    sl.get_ctl(seed, pixel, sample, bounce);
+    float cost;
+    const V3 pix = end_of_sample(fa, sl, bounce, cost, phash);
+    const auto& ff = sl.late_frame(fa);  // the frame's arguments, possibly loaded only here
+    V3 cc = g_pow(pix / (float)ff.spp, 1.0f / 2.2f);
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int n = 0;
+    if (!ff.reset) {
+        a = ff.accum[pixel];
+        n = ff.counts[pixel];
     }
+    a.x += cc.x; a.y += cc.y; a.z += cc.z; a.w += 1.0f;
+    n += 1;
+    ff.accum[pixel] = a;
+    ff.counts[pixel] = n;
+    ff.bgra[pixel] = resolve_pixel(a, n);
+    if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
+    const int py = (int)(pixel / (uint32_t)ff.width);
+    report_pixel_cost(ff, (int)pixel - py * ff.width, py, (uint32_t)cost);
 }
 
 // A slot's first sample of pixel (x, y): seed (raytracer.comp:959-961), empty pixel sum.
