@@ -1,5 +1,5 @@
 // rt_pool.hip — the pooled form of the path tracer for gfx950 (MI355X): one persistent
-// launch per frame in which every workgroup owns a pool of kPool path slots (1408 for its 1024 lanes),
+// launch per frame in which every workgroup owns a pool of kPool path slots (1392 for its 1024 lanes),
 // keeps their hot state in LDS and regroups them continuously through queues in LDS.
 //
 // One frame = one execution of shaders/raytracer.comp::main for every pixel this context
@@ -36,7 +36,7 @@ namespace {
 #define RT_POOL_THREADS 1024
 #endif
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 1408
+#define RT_POOL_SLOTS 1392
 #endif
 #ifndef RT_POOL_STACK
 #define RT_POOL_STACK 8
@@ -50,7 +50,7 @@ constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
 constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
-enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, Q_LIT = 4, Q_PIXEL = 5, kQueues = 6 };
+enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, Q_LIT = 4, Q_PIXEL = 5, Q_MISS = 6, kQueues = 7 };
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -66,18 +66,19 @@ struct PoolLds {
     uint32_t flags[(kPool + 3) / 4];  // one byte per slot: LF_* of the sample's light query (changed by LDS atomics on the word)
     // queues
     uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
-    // What every wave polls once per round, in one 32-byte block (two 16-byte LDS reads):
+    // What every wave polls once per round, in one 48-byte block (three 16-byte LDS reads):
     // hc[q] = next ring position to pop << 16 | entries published and not yet claimed (one word, so
     // that a pop claims entries and advances the position with a single compare-and-swap);
     // live = slots that still carry a pixel; abort = a bound on waiting was exceeded (never in a
     // correct run).
-    alignas(16) uint32_t hc[kQueues];
+    alignas(16) uint32_t hc[8];      // kQueues used
     uint32_t live;
     uint32_t abort;
+    uint32_t ctl_pad[2];
     uint32_t tail[kQueues];          // next ring position to push
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
-static_assert(kQueues == 6 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
+static_assert(kQueues == 7 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
 static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing, "a queue entry is a 12-bit slot index plus a kind, and a ring holds every slot");
 static_assert(kThreads % 64 == 0 && kThreads <= 1024, "whole waves, one workgroup");
 
@@ -148,11 +149,12 @@ RT_DEV void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
 RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     const u32x4 a = *(const volatile lds_u32x4*)&L.hc[0];
     const u32x4 b = *(const volatile lds_u32x4*)&L.hc[4];
+    const u32x4 d = *(const volatile lds_u32x4*)&L.live;
     PoolCtl c;
     c.count[0] = a.x & 0xffffu; c.count[1] = a.y & 0xffffu; c.count[2] = a.z & 0xffffu; c.count[3] = a.w & 0xffffu;
-    c.count[4] = b.x & 0xffffu; c.count[5] = b.y & 0xffffu;
-    c.live = b.z;
-    c.abort = b.w;
+    c.count[4] = b.x & 0xffffu; c.count[5] = b.y & 0xffffu; c.count[6] = b.z & 0xffffu;
+    c.live = d.x;
+    c.abort = d.y;
     return c;
 }
 
@@ -304,14 +306,15 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow), kShortStack, kThreads};
 
     for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
-    if (tid < kQueues) { L.hc[tid] = 0; L.tail[tid] = 0; }
+    if (tid < 8) L.hc[tid] = 0;
+    if (tid < kQueues) L.tail[tid] = 0;
     // A frame with fewer pixels than the pools have slots is shared out evenly: every workgroup fills
     // only its share of slots (the rest stay dead), so that all CUs get work.
     // `slots_cap` (a multiple of the waves, at most kPool) limits the paths in flight further: a scene that
     // overflows the caches runs faster with fewer rays competing for them.
     const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
     const uint32_t per_wave = share >= (uint32_t)slots_cap ? (uint32_t)slots_cap / (uint32_t)kWaves : (share + kWaves - 1u) / kWaves;
-    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
         const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
@@ -355,6 +358,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (ctl.count[Q_END] > best) { best = ctl.count[Q_END]; q = Q_END; }
         if (ctl.count[Q_LIT] > best) { best = ctl.count[Q_LIT]; q = Q_LIT; }
         if (ctl.count[Q_PIXEL] > best) { best = ctl.count[Q_PIXEL]; q = Q_PIXEL; }
+        if (ctl.count[Q_MISS] > best) { best = ctl.count[Q_MISS]; q = Q_MISS; }
         const unsigned long long busy = __ballot(slot >= 0);
         const bool nothing_to_search = (busy == 0ull) && ctl.count[Q_SEARCH] == 0u;
         // a job is worth a wave when it is full; when the pool runs thin (end of the frame, or fewer
@@ -368,7 +372,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             const uint32_t n_items = queue_pop(L, q, ~0ull, best >= job_thresh ? job_thresh : 1u, item, got);
             if (n_items == 0u) continue;
             guard = 0;
-            const int jk = q == Q_FIRST ? 0 : q == Q_NEXT ? 1 : q == Q_LIT ? 2 : 3;  // STATS index: first-bounce, later-bounce, light's term, sample / pixel end
+            const int jk = q == Q_FIRST ? 0 : q == Q_NEXT ? 1 : q == Q_LIT ? 2 : 3;  // STATS index: first-bounce, later-bounce, light's term, sample / pixel end / misses
             if (STATS) job_stats[jk] += ((unsigned long long)n_items << 32) | 1ull;
             const uint32_t i = item & 0xfffu;
             const PoolSlot ps{L, cold_base + 4 * i, i};
@@ -385,7 +389,9 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             } else {
                 bool ends = false, retry = false;
                 int light_kind = 0;
-                if (got) ends = shade_item(sc, fa, ps, recs, q - Q_FIRST, light_kind, retry);
+                // (a ray that missed everything comes through its own queue, so that the hits' stages run full: its
+                // entry says whether it was a sample's first ray)
+                if (got) ends = shade_item(sc, fa, ps, recs, q == Q_MISS ? (int)(item >> 12) : q - Q_FIRST, light_kind, retry);
                 // a first hit may send a light query on its way beside the path
                 if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12));
                 // the path: its next ray, or its end - where the sample waits for its light query if that is still
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 int to = -1;
                 uint32_t entry = i;
                 if (got && retry) {
-                    to = Q_NEXT;
+                    to = q; entry = item;  // back where it came from, as it came
                 } else if (got && !ends) {
                     to = Q_SEARCH; entry = i | (1u << 12);
                 } else if (got) {
@@ -418,10 +424,12 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (ended != 0ull) {
             const bool mine = (tv.cur == kTravDone && slot >= 0);
             int to = -1;
-            if (mine && skind < 2) {  // a path ray: its hit goes to the stage of its kind
+            uint32_t entry = (uint32_t)slot;
+            if (mine && skind < 2) {  // a path ray: its hit goes to the stage of its kind, a miss to the misses' stage
                 L.hit_t[slot] = tv.best_t;
                 L.hit_idx[slot] = tv.best_idx;
-                to = Q_FIRST + skind;
+                to = tv.best_idx < 0 ? Q_MISS : Q_FIRST + skind;
+                entry = (uint32_t)slot | (tv.best_idx < 0 ? (uint32_t)skind << 12 : 0u);
             }
             if (hash_mode && mine && skind >= 2)  // the query's hit id, for the per-pixel hash
                 ((int*)(cold_base + 4 * slot + 3))[3] = tv.best_idx >= 0 ? __float_as_int(recs[3 * tv.best_idx].w) : -1;
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 const PoolSlot ps{L, cold_base + 4 * slot, (uint32_t)slot};
                 if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = end_queue(ps, visible ? LF_LIT : 0u);
             }
-            queue_push_any(L, to, (uint32_t)slot);
+            queue_push_any(L, to, entry);
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
