@@ -177,24 +177,30 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
 }
 
 // The same for several queues at once: every lane names its queue (0..kQueues-1, or -1 for
-// nothing) and its item; lanes 0..kQueues-1 reserve for one queue each, so the wave pays one LDS
-// atomic round trip however many queues receive entries.
+// nothing) and its item; lane k reserves for queue k, so the wave pays one LDS atomic round trip
+// however many queues receive entries.  MASK: the queues this call site can name (the others cost nothing).
+template <unsigned MASK>
 RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
     unsigned long long m[kQueues];
     unsigned long long any = 0ull;
+#pragma unroll
     for (int k = 0; k < kQueues; ++k) {
-        m[k] = __ballot(q == k);
+        m[k] = (MASK >> k) & 1u ? __ballot(q == k) : 0ull;
         any |= m[k];
     }
     if (any == 0ull) return;
     const int lane = lane_id();
     uint32_t n_mine = 0;
-    for (int k = 0; k < kQueues; ++k) n_mine = (lane == k) ? (uint32_t)__popcll(m[k]) : n_mine;
+#pragma unroll
+    for (int k = 0; k < kQueues; ++k)
+        if ((MASK >> k) & 1u) n_mine = (lane == k) ? (uint32_t)__popcll(m[k]) : n_mine;
     uint32_t pos = 0;
     if (lane < kQueues && n_mine != 0u) pos = atomicAdd(&L.tail[lane], n_mine);
     uint32_t base = 0;
     unsigned long long mk = 0ull;
+#pragma unroll
     for (int k = 0; k < kQueues; ++k) {
+        if (!((MASK >> k) & 1u)) continue;
         const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pos, k);
         if (q == k) { base = pk; mk = m[k]; }
     }
@@ -385,7 +391,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 queue_push(L, Q_SEARCH, got, i);  // kind 0: the next sample's first ray
             } else if (q == Q_LIT) {
                 if (got) lit_item(sc, ps);
-                queue_push_any(L, got ? end_queue(ps, 0u) : -1, i);
+                queue_push_any<(1u << Q_END) | (1u << Q_PIXEL)>(L, got ? end_queue(ps, 0u) : -1, i);
             } else {
                 bool ends = false, retry = false;
                 int light_kind = 0;
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     if (f & LF_PENDING) { f = ps.or_flags(LF_PATH_DONE); last = (f & LF_DONE) != 0u; }
                     if (last) to = end_queue(ps, f);
                 }
-                queue_push_any(L, to, entry);
+                queue_push_any<(1u << Q_SEARCH) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry);
                 // items put back (they wait for their light query to be taken by a lane or, with the per-pixel hash,
                 // to report its hit id) must not keep the waves from the searching that would end the wait
                 search_first = __ballot(got && retry) != 0ull;
@@ -442,7 +448,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 const PoolSlot ps{L, cold_base + 4 * slot, (uint32_t)slot};
                 if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = end_queue(ps, visible ? LF_LIT : 0u);
             }
-            queue_push_any(L, to, entry);
+            queue_push_any<(1u << Q_FIRST) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry);
             if (mine) slot = -1;
         }
         const unsigned long long idle = __ballot(slot < 0);
