@@ -279,7 +279,8 @@ enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once t
        RT_OPT_POOL_PER_CU = 6,    /* pooled kernel: cap on workgroups per CU (0 = what fits, ..8)                            */
        RT_OPT_BVH_MAX_LEAF = 7,   /* most primitives per BVH leaf (1..8, 4)                                                  */
        RT_OPT_POOL_SLOTS = 8,     /* pooled kernel: paths in flight per workgroup (0 = chosen by scene size, ..1408)         */
-       RT_OPT_BVH_TREELET = 9 };  /* BVH node layout: levels per treelet (0 / 1 = depth-first order, ..16); next upload      */
+       RT_OPT_BVH_TREELET = 9,    /* BVH node layout: levels per treelet (0 / 1 = depth-first order, ..16); next upload      */
+       RT_OPT_BVH_WIDTH = 10 };   /* pooled kernel: children per node of the tree it walks (2, 4; 0 = 4 when its stack fits) */
 int rt_set_option(RtContext* ctx, int option, int value);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);
@@ -445,6 +446,11 @@ int rt_controller_end_frame(RtController* c, double now_seconds);
  * exactly one leaf, boxes nested, depth within the traversal limit; RT_ERR_UNSUPPORTED if
  * not) and reports node count, depth, primitive count and SAH cost. */
 int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost);
+/* Builds the four-wide form of that tree (what the pooled kernel walks on scenes beyond the caches, see
+ * RT_OPT_BVH_WIDTH), checks that it holds exactly the binary tree's leaves (RT_ERR_UNSUPPORTED if not) and
+ * reports its node count, depth and the most stack entries a traversal of it can hold.  No GPU needed.
+ * No counterpart in the reference, which has no acceleration structure (raytracer.comp:469-508). */
+int rt_scene_wide_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* stack_need);
 /* Fingerprint (FNV-1a) of the node array and leaf order rt_upload_scene would build for this scene:
  * the build is deterministic, whatever the number of host threads it uses. */
 int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash);

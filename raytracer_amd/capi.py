@@ -41,7 +41,7 @@ RT_SKY_GREY, RT_SKY_DAY, RT_SKY_NIGHT, RT_SKY_WHITE, RT_SKY_BLACK = 0, 1, 2, 3, 
 RT_PIPELINE_SINGLE, RT_PIPELINE_POOLED = 0, 2
 RT_GROUP_STRIPS, RT_GROUP_SAMPLES = 0, 1
 RT_OPT_EXIT_QUOTA_PCT, RT_OPT_REFILL_MIN, RT_OPT_POOL_BURST, RT_OPT_POOL_JOB_MIN = 1, 2, 3, 4
-RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF, RT_OPT_POOL_SLOTS, RT_OPT_BVH_TREELET = 5, 6, 7, 8, 9
+RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF, RT_OPT_POOL_SLOTS, RT_OPT_BVH_TREELET, RT_OPT_BVH_WIDTH = 5, 6, 7, 8, 9, 10
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1
@@ -206,6 +206,7 @@ PROTOTYPES = {
     "rt_controller_end_frame": (C.c_int, [_P, C.c_double]),
     "rt_scene_bvh_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_float)]),
+    "rt_scene_wide_bvh_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_scene_bvh_hash": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
 }
 

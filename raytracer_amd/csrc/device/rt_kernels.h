@@ -10,7 +10,7 @@ namespace rtd {
 struct DeviceScene {
     const float4* prims_bvh;   // 3 float4 per primitive, BVH leaf order
     const float4* prims_flat;  // 3 float4 per primitive, the reference's loop order
-    const float4* nodes;       // 4 float4 per BVH node, node 0 = root
+    const float4* nodes;       // 4 float4 per BVH node, node 0 = root (the pooled kernel's four-wide search: 8 float4 per node)
     const float4* materials;   // 5 float4 per material (raytracer.comp:54-82)
     const float4* lights;      // 3 float4 per light    (raytracer.comp:47-52)
     const float4* triangles;   // 4 float4 per triangle (raytracer.comp:90-96), for stored normals and light sampling
@@ -89,14 +89,17 @@ struct PathPool {
     float4* cold;
     uint32_t* stack_overflow;
     uint32_t n_slots;
+    uint32_t overflow_words;  // per lane
 };
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
                          hipStream_t stream);
 // The pooled pipeline: one persistent launch, path slots regrouped through LDS queues.
 int pool_slots_per_block();
-int pool_overflow_per_lane();
+int pool_overflow_per_lane();  // the least a lane's overflow area holds; a four-wide tree may need more (pool_overflow_for)
+int pool_overflow_for(int stack_need);  // words per lane for a tree whose traversal holds up to stack_need entries
 int pool_threads_per_block();
+// accel: 0 the flat loops, 1 the binary tree, 2 the four-wide tree (sc.nodes must then be the wide nodes)
 // per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid)
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,

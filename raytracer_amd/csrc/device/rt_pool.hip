@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     float4* const cold_base = pp.cold + (size_t)blockIdx.x * kPool * 4;
-    const float4* __restrict__ recs = (ACCEL == 1) ? sc.prims_bvh : sc.prims_flat;
-    const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * kOverflow), kShortStack, kThreads};
+    const float4* __restrict__ recs = (ACCEL >= 1) ? sc.prims_bvh : sc.prims_flat;
+    const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * pp.overflow_words), kShortStack, kThreads};
 
     for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
     if (tid < 8) L.hc[tid] = 0;
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     (void)PoolSlot{L, cold_base + 4 * slot, (uint32_t)slot}.or_flags(LF_FETCHED);
                 }
                 n_rays++;
-                if (ACCEL == 1) {
+                if (ACCEL >= 1) {
                     sl = make_slab(ro, rd);
                     trav_reset(tv, 0);  // node 0 is always an internal node
                     // A light query only asks whether the nearest hit lies within 0.1 of the sampled point's
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         }
         guard = 0;
         const unsigned long long t_steps = STATS ? __builtin_readcyclecounter() : 0ull;
-        if (ACCEL == 1) {
+        if (ACCEL >= 1) {
             for (int it = 0; it < burst; ++it) {
                 const unsigned long long m_node = __ballot(tv.cur >= 0 && tv.cur != kTravDone);
                 const unsigned long long m_leaf = __ballot(tv.cur < 0);
@@ -508,7 +508,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
                     if (tv.cur >= 0 && tv.cur != kTravDone) {
                         const int sp_before = tv.sp;
-                        trav_node_step(sc.nodes, sl, stack, tv);
+                        if (ACCEL == 2) trav_wide_step(sc.nodes, sl, stack, tv);
+                        else trav_node_step(sc.nodes, sl, stack, tv);
                         if (STATS) n_nodes++;
                         if (STATS && tv.sp > sp_before) deep_pushes += (sp_before >= 4 ? (1ull << 32) : 0ull) + (sp_before >= 8 ? 1ull : 0ull) + (sp_before >= 6 ? (1ull << 16) : 0ull);
                     }
@@ -541,7 +542,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (STATS) {
             atomicAdd((unsigned long long*)(fa.counters + 4), nn);
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);
-            atomicAdd((unsigned long long*)(fa.counters + 16), nn + (ACCEL == 1 ? nt : 0ull));
+            atomicAdd((unsigned long long*)(fa.counters + 16), nn + (ACCEL >= 1 ? nt : 0ull));
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
             atomicAdd((unsigned long long*)(fa.counters + 40), busy_iters);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), job_stats[k]);
@@ -559,6 +560,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
 
 typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int);
 PoolKernel pick_kernel(int accel, bool stats) {
+    if (accel == 2) return stats ? pool_kernel<2, true> : pool_kernel<2, false>;
     return accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
 }
 constexpr size_t kStackLds = (size_t)kShortStack * kThreads * sizeof(uint32_t);
@@ -568,6 +570,7 @@ constexpr size_t kStackLds = (size_t)kShortStack * kThreads * sizeof(uint32_t);
 int pool_slots_per_block() { return kPool; }
 int pool_threads_per_block() { return kThreads; }
 int pool_overflow_per_lane() { return kOverflow; }
+int pool_overflow_for(int stack_need) { return stack_need + 1 - kShortStack > kOverflow ? stack_need + 1 - kShortStack : kOverflow; }
 
 // Workgroups of the pooled launch: as many as are resident at once, fewer when the image
 // is small.  The path pool must hold grid * pool_slots_per_block() cold records and

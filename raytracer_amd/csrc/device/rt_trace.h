@@ -183,6 +183,53 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
     else trav_pop(tv, stack);
 }
 
+// The same for a four-wide node (8 float4: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of the four children, their
+// cursor words, padding): slab-test the four children, descend into the nearest one hit, push the others,
+// farthest first.  An empty place holds the cursor word kTravDone and is never entered.
+template <typename Stack>
+RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
+    const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;
+    const float4 lx = nd[0], ly = nd[1], lz = nd[2];
+    const float4 hx = nd[3], hy = nd[4], hz = nd[5];
+    const float4 w = nd[6];
+    float t0, t1, t2, t3;
+    int c0 = __float_as_int(w.x), c1 = __float_as_int(w.y), c2 = __float_as_int(w.z), c3 = __float_as_int(w.w);
+#define RT_WIDE_CHILD(T, C, F)                                                                              \
+    {                                                                                                         \
+        const float ax = __builtin_fmaf(lx.F, sl.ix, sl.ox), bx = __builtin_fmaf(hx.F, sl.ix, sl.ox);       \
+        const float ay = __builtin_fmaf(ly.F, sl.iy, sl.oy), by = __builtin_fmaf(hy.F, sl.iy, sl.oy);       \
+        const float az = __builtin_fmaf(lz.F, sl.iz, sl.oz), bz = __builtin_fmaf(hz.F, sl.iz, sl.oz);       \
+        const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));          \
+        const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tv.best_t));     \
+        T = ((tmin <= tmax * 1.000001f) && (C != kTravDone)) ? tmin : kInf;                                  \
+    }
+    RT_WIDE_CHILD(t0, c0, x)
+    RT_WIDE_CHILD(t1, c1, y)
+    RT_WIDE_CHILD(t2, c2, z)
+    RT_WIDE_CHILD(t3, c3, w)
+#undef RT_WIDE_CHILD
+    const int n_hit = (int)(t0 < kInf) + (int)(t1 < kInf) + (int)(t2 < kInf) + (int)(t3 < kInf);
+    // nearest first (children not hit carry +inf and end up last)
+#define RT_WIDE_ORDER(TA, CA, TB, CB)                  \
+    {                                                    \
+        const bool swap = TB < TA;                       \
+        const float tt = TA; const int cc = CA;          \
+        TA = swap ? TB : TA; CA = swap ? CB : CA;        \
+        TB = swap ? tt : TB; CB = swap ? cc : CB;        \
+    }
+    RT_WIDE_ORDER(t0, c0, t1, c1)
+    RT_WIDE_ORDER(t2, c2, t3, c3)
+    RT_WIDE_ORDER(t0, c0, t2, c2)
+    RT_WIDE_ORDER(t1, c1, t3, c3)
+    RT_WIDE_ORDER(t1, c1, t2, c2)
+#undef RT_WIDE_ORDER
+    if (n_hit >= 4) { stack.put(tv.sp, (uint32_t)c3); tv.sp++; }
+    if (n_hit >= 3) { stack.put(tv.sp, (uint32_t)c2); tv.sp++; }
+    if (n_hit >= 2) { stack.put(tv.sp, (uint32_t)c1); tv.sp++; }
+    if (n_hit >= 1) tv.cur = c0;
+    else trav_pop(tv, stack);
+}
+
 // Test the next primitive of the leaf under the cursor.
 template <typename Stack>
 RT_DEV void trav_leaf_step(const float4* __restrict__ prims, V3 ro, V3 rd, const Stack& stack, Trav& tv) {

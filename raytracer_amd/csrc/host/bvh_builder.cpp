@@ -457,6 +457,128 @@ void layout_treelets(HostBvh& bvh, int levels) {
     bvh.nodes.swap(out);
 }
 
+namespace {
+struct WideRef {
+    int32_t child, count;  // as in BvhNode: count > 0 a leaf, count == 0 an internal node
+    float lo[3], hi[3];
+    float area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+void child_refs(const BvhNode& n, std::vector<WideRef>& out) {
+    for (int side = 0; side < 2; ++side) {
+        WideRef r;
+        r.child = side ? n.child1 : n.child0;
+        r.count = side ? n.count1 : n.count0;
+        if (r.child < 0) continue;  // an unused place of a one-child root
+        for (int k = 0; k < 3; ++k) {
+            r.lo[k] = side ? n.lo1[k] : n.lo0[k];
+            r.hi[k] = side ? n.hi1[k] : n.hi0[k];
+        }
+        out.push_back(r);
+    }
+}
+}  // namespace
+
+void collapse_wide(const HostBvh& bvh, HostWideBvh& out) {
+    out.nodes.clear();
+    out.stack_need = 0;
+    out.depth = 0;
+    if (bvh.nodes.empty()) return;
+    // depth-first, parents before children, without recursion: (binary node, wide node that stands for it)
+    struct Todo { int32_t binary, wide, depth; };
+    std::vector<Todo> todo;
+    std::vector<int32_t> need_above;  // per wide node: stack entries held by its ancestors when it is entered
+    out.nodes.emplace_back();
+    need_above.push_back(0);
+    todo.push_back({0, 0, 1});
+    std::vector<WideRef> refs;
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        refs.clear();
+        child_refs(bvh.nodes[(size_t)t.binary], refs);
+        while (refs.size() < 4) {
+            int best = -1;
+            for (size_t k = 0; k < refs.size(); ++k)
+                if (refs[k].count == 0 && (best < 0 || refs[k].area() > refs[(size_t)best].area())) best = (int)k;
+            if (best < 0) break;
+            const WideRef open = refs[(size_t)best];
+            refs.erase(refs.begin() + best);
+            child_refs(bvh.nodes[(size_t)open.child], refs);
+        }
+        WideNode w;
+        std::memset(&w, 0, sizeof w);
+        const int n = (int)refs.size();
+        const int32_t held = need_above[(size_t)t.wide] + (n > 0 ? n - 1 : 0);
+        if (held > out.stack_need) out.stack_need = held;
+        if (t.depth > out.depth) out.depth = t.depth;
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) { w.child[k] = kWideUnused; continue; }
+            const WideRef& r = refs[(size_t)k];
+            w.lox[k] = r.lo[0]; w.loy[k] = r.lo[1]; w.loz[k] = r.lo[2];
+            w.hix[k] = r.hi[0]; w.hiy[k] = r.hi[1]; w.hiz[k] = r.hi[2];
+            if (r.count > 0) {
+                w.child[k] = (int32_t)(0x80000000u | ((uint32_t)(r.count - 1) << 28) | (uint32_t)r.child);
+            } else {
+                w.child[k] = (int32_t)out.nodes.size();
+                out.nodes.emplace_back();
+                need_above.push_back(held);
+                todo.push_back({r.child, w.child[k], t.depth + 1});
+            }
+        }
+        out.nodes[(size_t)t.wide] = w;
+    }
+}
+
+bool validate_wide(const HostBvh& bvh, const HostWideBvh& wide, std::string* err) {
+    if (wide.nodes.empty()) return fail(err, "no wide root");
+    // the binary tree's leaves, by first record
+    std::vector<int32_t> leaf_count(bvh.prims.size() + 1, 0);
+    size_t n_leaves = 0;
+    for (const BvhNode& n : bvh.nodes) {
+        if (n.child0 >= 0 && n.count0 > 0) { leaf_count[(size_t)n.child0] = n.count0; n_leaves++; }
+        if (n.child1 >= 0 && n.count1 > 0) { leaf_count[(size_t)n.child1] = n.count1; n_leaves++; }
+    }
+    std::vector<int> seen(wide.nodes.size(), 0);
+    struct Item { int32_t node, above, depth; };
+    std::vector<Item> stack = {{0, 0, 1}};
+    seen[0] = 1;
+    size_t leaves = 0;
+    int32_t need = 0, depth = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        const WideNode& w = wide.nodes[(size_t)it.node];
+        int n = 0;
+        for (int k = 0; k < 4; ++k) n += w.child[k] != kWideUnused;
+        const int32_t held = it.above + (n > 0 ? n - 1 : 0);
+        need = held > need ? held : need;
+        depth = it.depth > depth ? it.depth : depth;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = w.child[k];
+            if (c == kWideUnused) continue;
+            if (!(w.lox[k] <= w.hix[k] && w.loy[k] <= w.hiy[k] && w.loz[k] <= w.hiz[k])) return fail(err, "wide child box inverted");
+            if (c < 0) {
+                const size_t first = (size_t)(c & 0x0fffffff);
+                const int32_t count = ((c >> 28) & 7) + 1;
+                if (first >= bvh.prims.size() || leaf_count[first] != count) return fail(err, "wide leaf is not a leaf of the binary tree");
+                leaf_count[first] = 0;  // once only
+                leaves++;
+            } else {
+                if ((size_t)c >= wide.nodes.size() || seen[(size_t)c]) return fail(err, "wide node index out of range or reached twice");
+                seen[(size_t)c] = 1;
+                stack.push_back({c, held, it.depth + 1});
+            }
+        }
+    }
+    if (leaves != n_leaves) return fail(err, "wide tree lost leaves");
+    for (int v : seen) if (!v) return fail(err, "unreachable wide node");
+    if (need != wide.stack_need || depth != wide.depth) return fail(err, "wide stack_need / depth do not match the tree");
+    return true;
+}
+
 bool validate_bvh(const HostBvh& bvh, std::string* err) {
     if (bvh.nodes.empty()) return fail(err, "no root node");
     std::vector<int> node_seen(bvh.nodes.size(), 0), prim_seen(bvh.prims.size(), 0);

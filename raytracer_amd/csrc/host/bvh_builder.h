@@ -72,6 +72,34 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_lea
 // first); levels <= 1 keeps the builder's depth-first order.  Same tree, same traversal, other addresses.
 void layout_treelets(HostBvh& bvh, int levels);
 
+// Four-wide form of the same tree for the pooled kernel: a node holds up to four children's boxes, one
+// component of all four per 16-byte load, and the children as the traversal's cursor words (an internal
+// node's index; bit 31 | (count - 1) << 28 | first record for a leaf; kWideUnused for an empty place, whose
+// box is all zeros).  128 bytes: one cache line per visit, about half the visits of the binary tree.
+struct WideNode {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
+static const int32_t kWideUnused = 0x7fffffff;
+
+struct HostWideBvh {
+    std::vector<WideNode> nodes;  // nodes[0] is the root
+    int32_t stack_need = 0;       // most entries a traversal can hold at once (every node on a path entered through all its children)
+    int32_t depth = 0;
+};
+
+// Collapses the binary tree: a node's children are replaced, largest box first, by their own children
+// until four are held.  Every child box is one the binary tree stores, so a traversal tests a superset
+// of the leaves the binary traversal tests, in another order: the same nearest hit.
+void collapse_wide(const HostBvh& bvh, HostWideBvh& out);
+
+// Every primitive range of the binary tree's leaves appears in exactly one leaf word of the wide tree, every
+// node is reachable once, and stack_need / depth are what the stored tree implies.
+bool validate_wide(const HostBvh& bvh, const HostWideBvh& wide, std::string* err);
+
 // Structural self-check: every node reachable exactly once, every primitive in exactly one
 // leaf, every leaf box contains its primitives, every stored child box contains the boxes
 // stored below it, depth and leaf size within the traversal kernel's limits.

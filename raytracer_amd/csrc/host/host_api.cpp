@@ -214,6 +214,28 @@ int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_
     return RT_OK;
 }
 
+// The four-wide form of the scene's tree (what the pooled kernel walks on large scenes), built and checked.
+int rt_scene_wide_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* stack_need) {
+    if (!s) return RT_ERR_INVALID_ARGUMENT;
+    const Scene& sc = s->scene;
+    rt::SceneArrays a;
+    a.spheres = sc.sphereVec.data();     a.n_spheres = sc.total_spheres;
+    a.triangles = sc.triangleVec.data(); a.n_triangles = sc.total_triangles;
+    a.vertices = sc.vertexVec.data();    a.n_vertices = (int32_t)sc.vertexVec.size();
+    a.indices = sc.indexVec.data();      a.n_indices = (int32_t)sc.indexVec.size();
+    a.meshes = sc.meshVec.data();        a.n_meshes = sc.total_meshes;
+    rt::HostBvh bvh;
+    rt::HostWideBvh wide;
+    std::string err;
+    if (!rt::build_bvh(a, bvh, &err)) return RT_ERR_INVALID_ARGUMENT;
+    rt::collapse_wide(bvh, wide);
+    if (!rt::validate_wide(bvh, wide, &err)) return RT_ERR_UNSUPPORTED;
+    if (n_nodes) *n_nodes = (int32_t)wide.nodes.size();
+    if (depth) *depth = wide.depth;
+    if (stack_need) *stack_need = wide.stack_need;
+    return RT_OK;
+}
+
 // FNV-1a over the BVH's node array and leaf order (what rt_upload_scene would copy to the device).
 int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash) {
     if (!s || !hash) return RT_ERR_INVALID_ARGUMENT;

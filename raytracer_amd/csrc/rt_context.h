@@ -19,6 +19,7 @@ struct RtOptions {
     int tile_classes = 16;    // cost classes of the frame-to-frame tile order
     int pool_per_cu = 0;      // pooled kernel: cap on workgroups per CU (0: what fits)
     int bvh_max_leaf = 4;     // builder: most primitives per leaf (takes effect at the next rt_upload_scene)
+    int bvh_width = 0;        // pooled kernel: children per node of the tree it walks (2, 4; 0: four when its stack fits)
     int bvh_treelet = 0;      // node layout: levels per treelet (0 / 1: depth-first order; next rt_upload_scene)
 };
 
@@ -36,11 +37,13 @@ struct RtContext {
     void* d_prims_bvh = nullptr;
     void* d_prims_flat = nullptr;
     void* d_nodes = nullptr;
+    void* d_nodes_wide = nullptr;  // the four-wide form of the same tree (pooled kernel)
     void* d_materials = nullptr;
     void* d_lights = nullptr;
     void* d_triangles = nullptr;
     int32_t n_prims = 0, n_spheres = 0, n_triangles = 0, n_meshes = 0, n_lights = 0, n_materials = 0;
     int32_t bvh_nodes = 0, bvh_depth = 0;
+    int32_t wide_nodes = 0, wide_stack_need = 0;
 
     // framebuffer
     int32_t width = 0, height = 0;

@@ -121,6 +121,11 @@ class Scene:
         self._chk(self._lib.rt_scene_bvh_info(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(s)), "rt_scene_bvh_info")
         return {"nodes": n.value, "depth": d.value, "prims": p.value, "sah_cost": s.value}
 
+    def wide_bvh_info(self) -> dict:
+        n, d, k = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._lib.rt_scene_wide_bvh_info(self._h, C.byref(n), C.byref(d), C.byref(k)), "rt_scene_wide_bvh_info")
+        return {"nodes": n.value, "depth": d.value, "stack_need": k.value}
+
     def bvh_hash(self) -> int:
         h = C.c_uint64()
         self._chk(self._lib.rt_scene_bvh_hash(self._h, C.byref(h)), "rt_scene_bvh_hash")

@@ -387,6 +387,28 @@ def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, st
     assert owned.any() and (a["counts"][owned] == 3).all()
 
 
+@pytest.mark.parametrize("kind", ["teapot", "mixed"])
+def test_pooled_tree_widths_agree(ctx, teapot, kind):
+    """The pooled kernel walks the four-wide form of the tree unless told otherwise (RT_OPT_BVH_WIDTH): both
+    widths hold the same leaves behind the same boxes, so they must agree bit for bit - with each other, and
+    (but for edge ties) with the oracle."""
+    from helpers import DEBUG_FLAGS
+    W, H = 120, 68
+    s = teapot if kind == "teapot" else _custom_scene(kind)
+    o = oracle_frames(s, W, H, spp=2, max_bounces=5)
+    got = {}
+    try:
+        for width in (2, 4):
+            ctx.set_option(capi.RT_OPT_BVH_WIDTH, width)
+            got[width] = gpu_frames(ctx, s, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+    finally:
+        ctx.set_option(capi.RT_OPT_BVH_WIDTH, 0)
+    assert_identical(got[4], got[2])
+    assert_identical_but_edge_ties(got[4], o)
+    with pytest.raises(Exception):
+        ctx.set_option(capi.RT_OPT_BVH_WIDTH, 3)
+
+
 @pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
 def test_full_size_frames_agree_across_pipelines(ctx, workload):
     """BASELINE.json's full sizes (C2: 1920x1080, 4 spp x 20 bounces on the star scene; C3: 1920x1080,

@@ -169,3 +169,15 @@ def test_parallel_bvh_build_lays_the_tree_out_as_the_serial_build_does(monkeypat
     assert parallel == serial
     assert info["prims"] > 1_000_000
     print(f"1.07 M triangles: parallel build {t1 - t0:.2f} s, serial {t3 - t2:.2f} s")
+
+
+def test_wide_tree_holds_the_binary_trees_leaves():
+    """The four-wide form of the tree, which the pooled kernel walks: collapse + structural check (every leaf of
+    the binary tree exactly once, every node reachable once, stack need and depth as stored)."""
+    for preset in (capi.RT_SCENE_CORNELL_STAR, capi.RT_SCENE_CORNELL_TEAPOT, capi.RT_SCENE_PRESET1_TEAPOT):
+        s = Scene(preset)
+        b, w = s.bvh_info(), s.wide_bvh_info()  # raises if the structural validation fails
+        assert 0 < w["nodes"] <= b["nodes"]
+        assert w["depth"] <= b["depth"]
+        # a binary tree of depth d holds at most d - 1 entries; merging levels at most triples that
+        assert w["depth"] - 1 <= w["stack_need"] <= 3 * (b["depth"] - 1)
