@@ -515,9 +515,9 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     }
                 } else {
                     if (tv.cur < 0) {
-                        trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
+                        trav_leaf_step2(sc.prims_bvh, ro, rd, stack, tv);
                         if (tv.best_t < s_d - occl_bias) tv.cur = kTravDone;  // a light query is settled (never true for path rays)
-                        if (STATS) n_tests++;
+                        if (STATS) n_tests++;  // leaf steps (of one or two primitives)
                     }
                 }
             }

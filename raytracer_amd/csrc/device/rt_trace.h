@@ -13,11 +13,7 @@ RT_DEV bool surrounds(float x) { return 0.005f < x && kInf > x; }  // Interval(0
 // One primitive against one ray; keeps the winner under the reference's tie rules
 // (lower t; equal t: lower prio).  Triangle: raytracer.comp:366-406 / 412-449 with the two
 // edges precomputed; sphere: raytracer.comp:334-361.
-RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
-                             int& best_idx) {
-    const float4 A = recs[3 * idx + 0];
-    const float4 B = recs[3 * idx + 1];
-    const float4 C = recs[3 * idx + 2];
+RT_DEV void intersect_loaded(float4 A, float4 B, float4 C, int idx, V3 ro, V3 rd, float& best_t, int& best_prio, int& best_idx) {
     const int prio = __float_as_int(B.w);
     float t;
     if (__float_as_int(C.w) < 0) {  // sphere: A.xyz centre, B.x radius
@@ -54,6 +50,10 @@ RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3
         best_prio = prio;
         best_idx = idx;
     }
+}
+RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
+                             int& best_idx) {
+    intersect_loaded(recs[3 * idx + 0], recs[3 * idx + 1], recs[3 * idx + 2], idx, ro, rd, best_t, best_prio, best_idx);
 }
 
 // The reference's search: every primitive, in the order of its three loops.
@@ -238,6 +238,21 @@ RT_DEV void trav_leaf_step(const float4* __restrict__ prims, V3 ro, V3 rd, const
     intersect_record(prims, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
     if (left == 0) trav_pop(tv, stack);
     else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 1) << 28) | (uint32_t)(first + 1));
+}
+
+// Test the next two primitives of the leaf under the cursor (one, if it is the last): both records are
+// fetched at once, so a leaf costs half the round trips to memory.
+template <typename Stack>
+RT_DEV void trav_leaf_step2(const float4* __restrict__ prims, V3 ro, V3 rd, const Stack& stack, Trav& tv) {
+    const int first = tv.cur & 0x0fffffff;
+    const int left = (tv.cur >> 28) & 7;  // primitives after this one
+    const int second = first + (left > 0 ? 1 : 0);
+    const float4 A0 = prims[3 * first + 0], B0 = prims[3 * first + 1], C0 = prims[3 * first + 2];
+    const float4 A1 = prims[3 * second + 0], B1 = prims[3 * second + 1], C1 = prims[3 * second + 2];
+    intersect_loaded(A0, B0, C0, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
+    if (left > 0) intersect_loaded(A1, B1, C1, second, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
+    if (left <= 1) trav_pop(tv, stack);
+    else tv.cur = (int)(0x80000000u | ((uint32_t)(left - 2) << 28) | (uint32_t)(first + 2));
 }
 
 // Hit record of the winning primitive (raytracer.comp:354-358, 398-403, 454-461).
