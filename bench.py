@@ -225,10 +225,12 @@ def main() -> None:
             pixels_per_launch = W * H / world
             rays_per_launch = job_rays / args.steps / world
         if accel == capi.RT_ACCEL_BVH:
-            # per ray: 2 box tests (24 flop each) per visited node, 51 flop per triangle test;
-            # 64 B per visited node, 48 B per tested primitive record; + 48 B framebuffer per pixel
-            flops_per_ray = 24.0 * 2.0 * nodes_per_ray + 51.0 * tests_per_ray
-            bytes_per_ray = 64.0 * nodes_per_ray + 48.0 * tests_per_ray
+            # per ray: one box test (24 flop) per child of a visited node - 2 children in 64 B, or 4 in 128 B
+            # (the pooled kernel's four-wide tree) -, 51 flop per triangle test; 48 B per tested primitive
+            # record; + 48 B framebuffer per pixel
+            width = st.bvh_width if st.bvh_width in (2, 4) else 2
+            flops_per_ray = 24.0 * width * nodes_per_ray + 51.0 * tests_per_ray
+            bytes_per_ray = 32.0 * width * nodes_per_ray + 48.0 * tests_per_ray
         else:
             flops_per_ray = 30.0 * v.total_spheres + 51.0 * (n_prims - v.total_spheres)
             bytes_per_ray = 48.0 * n_prims
@@ -295,6 +297,7 @@ def main() -> None:
                 "flops_per_ray": flops_per_ray,
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
+                "children_per_node": st.bvh_width,
                 "prim_tests_per_ray": tests_per_ray,
                 "algorithmic_GBps": launch_bytes / (avg_kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,

@@ -157,7 +157,7 @@ enum { RT_PIPELINE_SINGLE = 0, RT_PIPELINE_POOLED = 2 };
 
 typedef struct RtStats {
     uint64_t rays;          /* nearest-hit searches in the last frame (always counted)         */
-    uint64_t nodes_visited; /* BVH nodes whose children were box-tested (needs TRAVERSAL_STATS)*/
+    uint64_t nodes_visited; /* BVH nodes whose children were box-tested (needs TRAVERSAL_STATS; see bvh_width) */
     uint64_t prims_tested;  /* primitive intersection tests (needs TRAVERSAL_STATS)            */
     uint64_t total_rays;    /* nearest-hit searches of ALL frames since rt_create              */
     /* the next five need TRAVERSAL_STATS (instrumented kernel, never the timed one):           */
@@ -183,6 +183,9 @@ typedef struct RtStats {
                                       step: the rest waited for the other kind of step)                      */
     uint64_t cycles_steps;  /* pooled pipeline with TRAVERSAL_STATS: the part of cycles_search spent in the bursts of
                                search steps (the rest: handing results in, taking new rays)                      */
+    int32_t  bvh_width;     /* children per node of the tree the last frame's kernel walked: 2, or 4 (pooled pipeline,
+                               RT_OPT_BVH_WIDTH; nodes_visited then counts four-wide nodes); 0 for the flat loops   */
+    int32_t  reserved;
 } RtStats;
 
 typedef struct RtContext RtContext;

@@ -107,7 +107,8 @@ class RtStats(C.Structure):
                 ("cycles_shade_parts", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
                 ("total_prims", C.c_int32), ("pipeline", C.c_int32),
-                ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64)]
+                ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64),
+                ("bvh_width", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RtSceneView(C.Structure):

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (flags & LF_LIT) return Q_LIT;
         return (L.cnt[ps.i] >> 16) >= last_sample ? Q_PIXEL : Q_END;
     };
-    uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, guard = 0;
+    uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, n_leaf_steps = 0, guard = 0;
     unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
@@ -515,9 +515,9 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     }
                 } else {
                     if (tv.cur < 0) {
+                        if (STATS) { n_leaf_steps++; n_tests += ((tv.cur >> 28) & 7) > 0 ? 2u : 1u; }
                         trav_leaf_step2(sc.prims_bvh, ro, rd, stack, tv);
                         if (tv.best_t < s_d - occl_bias) tv.cur = kTravDone;  // a light query is settled (never true for path rays)
-                        if (STATS) n_tests++;  // leaf steps (of one or two primitives)
                     }
                 }
             }
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     }
 
     // ---- counters: one atomic per wave
-    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests;
+    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests, nl = n_leaf_steps;
     unsigned long long dp4 = deep_pushes >> 32, dp6 = (deep_pushes >> 16) & 0xffffu, dp8 = deep_pushes & 0xffffu;
     for (int off = 32; off > 0; off >>= 1) {
         if (STATS) { dp4 += __shfl_down(dp4, off); dp6 += __shfl_down(dp6, off); dp8 += __shfl_down(dp8, off); }
@@ -534,6 +534,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (STATS) {
             nn += __shfl_down(nn, off);
             nt += __shfl_down(nt, off);
+            nl += __shfl_down(nl, off);
         }
     }
     if (lane == 0) {
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (STATS) {
             atomicAdd((unsigned long long*)(fa.counters + 4), nn);
             atomicAdd((unsigned long long*)(fa.counters + 6), nt);
-            atomicAdd((unsigned long long*)(fa.counters + 16), nn + (ACCEL >= 1 ? nt : 0ull));
+            atomicAdd((unsigned long long*)(fa.counters + 16), nn + nl);
             atomicAdd((unsigned long long*)(fa.counters + 18), wave_iters);
             atomicAdd((unsigned long long*)(fa.counters + 40), busy_iters);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 20 + 2 * k), job_stats[k]);

@@ -474,9 +474,11 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
                 accel = 2;
                 sc.nodes = (const float4*)c->d_nodes_wide;
             }
+            c->last_width = p.accel == RT_ACCEL_BVH ? width : 0;
             RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c),
                                        c->stream));
         } else {
+            c->last_width = p.accel == RT_ACCEL_BVH ? 2 : 0;
             RT_HIP(c, rtd::launch_render(sc_in, fa, p.accel, stats, c->cu_count, c->stream));
         }
     }
@@ -738,6 +740,8 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     out->bvh_depth = c->bvh_depth;
     out->total_prims = c->n_prims;
     out->pipeline = c->last_pipeline;
+    out->bvh_width = c->last_width;
+    out->reserved = 0;
     return rtapi::check_abandoned(c);
 }
 

@@ -30,6 +30,7 @@ struct RtContext {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
     int32_t last_pipeline = 0;
+    int32_t last_width = 0;  // children per node of the tree the last frame's kernel walked (0: the flat loops)
     RtOptions opt;
 
     // scene

@@ -11,11 +11,11 @@ timeout -k 10 300 python bench.py --workload c4 --no-cpu-baseline --steps 2 --wa
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_c3 --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/prof_c3.log 2>&1 || exit 1
 cp $out/prof_c3/*/*kernel_stats.csv $out/c3_kernel_stats.csv
 BENCH_ARGS="--pipeline pooled" bash tools/pmc_passes.sh $out/pmc_c3_pooled || exit 1
-python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<1, false>" 1 > $out/c3_pooled_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<2, false>" 1 > $out/c3_pooled_pmc.txt
 BENCH_ARGS="--pipeline single" bash tools/pmc_passes.sh $out/pmc_c3_single || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_single "render_kernel<1, false>" 1 > $out/c3_single_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline pooled" bash tools/pmc_passes.sh $out/pmc_c5_pooled || exit 1
-python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<1, false>" 1 > $out/c5_pooled_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<2, false>" 1 > $out/c5_pooled_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline single" bash tools/pmc_passes.sh $out/pmc_c5_single || exit 1
 python3 tools/pmc_summary.py $out/pmc_c5_single "render_kernel<1, false>" 1 > $out/c5_single_pmc.txt
 cat $out/bench_c3.json; head -4 $out/c3_kernel_stats.csv | cut -c1-160

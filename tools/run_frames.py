@@ -19,7 +19,7 @@ for f in range(n):
     ctx.render_frame(cam, s.push_constants(0.0, f, f == 0), make_params(spp, mb, capi.RT_ACCEL_BVH, strip[0], strip[1], strip[2], flags))
     ctx.sync()
     st = ctx.stats()
-    print(f"frame {f}: {st.kernel_ms:.3f} ms rays {st.rays} nodes/ray {st.nodes_visited/max(1,st.rays):.2f} leaf-steps/ray {st.prims_tested/max(1,st.rays):.2f} "
+    print(f"frame {f}: {st.kernel_ms:.3f} ms rays {st.rays} nodes/ray {st.nodes_visited/max(1,st.rays):.2f} tests/ray {st.prims_tested/max(1,st.rays):.2f} width {st.bvh_width} "
           f"occupancy {st.lane_iterations/(64*max(1,st.wave_iterations)):.3f}", flush=True)
     if mode == "pooled" and (flags & capi.RT_FLAG_TRAVERSAL_STATS):
         names = ["first-hit", "later-hit", "light-term", "sample-end/pixel-end/miss"]
