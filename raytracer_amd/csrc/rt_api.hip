@@ -47,7 +47,7 @@ namespace {
 constexpr size_t kScratchTiles = 128u * 1024u;      // 8x8 tiles of the largest frame (8.39 M pixels, e.g. 3840 x 2184)
 constexpr size_t kScratchStampBytes = 256;          // 8 words: what the stored tile order was made for
 constexpr size_t kScratchAuxBytes = 192u << 10;     // work area of the tile order kernels (rtd::tile_order_aux_bytes() <= this)
-constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1408 x 64 B records + 1024 x 24 stack words)
+constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1392 x 64 B records + 1024 x 24 stack words), rounded up
 constexpr size_t kScratchBytes = kScratchStampBytes + kScratchAuxBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 192 KiB + 256 B
 constexpr int kMaxDevices = 64;
 }  // namespace
@@ -425,7 +425,8 @@ static bool pooled_fits(const RtContext* c, const RtParams& p) {
 
 // Paths in flight per pooled workgroup: all the slots while the scene stays in the L2 caches; a scene far
 // beyond them (the 84 MB of the 1.07 M-triangle scene against 8 x 4 MB) runs faster with fewer rays
-// competing for the caches (measured on that scene: 1408 slots 15.8 ms, 1152 15.1, 896 14.7, 768 14.9).
+// competing for the caches (measured on that scene, binary tree: 1408 slots 15.8 ms, 1152 15.1, 896 14.7, 768 14.9;
+// four-wide tree: 1392 slots 14.0 ms, 1152 13.5, 896 13.2, 768 13.3).
 static int pool_slots(const RtContext* c) {
     if (c->opt.pool_slots > 0) return c->opt.pool_slots;
     const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
