@@ -183,33 +183,36 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
     else trav_pop(tv, stack);
 }
 
-// The same for a four-wide node (8 float4: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of the four children, their
+// The same for a four-wide node (8 float4: centre x, y, z and half extent x, y, z of the four children, their
 // cursor words, padding): slab-test the four children, descend into the nearest one hit, push the others,
-// farthest first.  An empty place holds the cursor word kTravDone and is never entered.
+// farthest first.  With centre and half extent the entry and exit distances need no min / max per axis:
+// (c * inv + off) -+ h * |inv|.  An empty place has a negative half extent: its entry lies behind its exit.
+// The boxes are padded by 1e-4 of the scene's scale on the host, a thousand times the rounding of these sums.
 template <typename Stack>
 RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
     const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;
-    const float4 lx = nd[0], ly = nd[1], lz = nd[2];
+    const float4 cx = nd[0], cy = nd[1], cz = nd[2];
     const float4 hx = nd[3], hy = nd[4], hz = nd[5];
     const float4 w = nd[6];
     float t0, t1, t2, t3;
     int c0 = __float_as_int(w.x), c1 = __float_as_int(w.y), c2 = __float_as_int(w.z), c3 = __float_as_int(w.w);
-#define RT_WIDE_CHILD(T, C, F)                                                                              \
+    const float ax = __builtin_fabsf(sl.ix), ay = __builtin_fabsf(sl.iy), az = __builtin_fabsf(sl.iz);
+#define RT_WIDE_CHILD(T, F)                                                                                  \
     {                                                                                                         \
-        const float ax = __builtin_fmaf(lx.F, sl.ix, sl.ox), bx = __builtin_fmaf(hx.F, sl.ix, sl.ox);       \
-        const float ay = __builtin_fmaf(ly.F, sl.iy, sl.oy), by = __builtin_fmaf(hy.F, sl.iy, sl.oy);       \
-        const float az = __builtin_fmaf(lz.F, sl.iz, sl.oz), bz = __builtin_fmaf(hz.F, sl.iz, sl.oz);       \
-        const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));          \
-        const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tv.best_t));     \
-        T = ((tmin <= tmax * 1.000001f) && (C != kTravDone)) ? tmin : kInf;                                  \
+        const float bx = __builtin_fmaf(cx.F, sl.ix, sl.ox), by = __builtin_fmaf(cy.F, sl.iy, sl.oy);       \
+        const float bz = __builtin_fmaf(cz.F, sl.iz, sl.oz);                                                \
+        const float nx = __builtin_fmaf(-hx.F, ax, bx), ny = __builtin_fmaf(-hy.F, ay, by), nz = __builtin_fmaf(-hz.F, az, bz); \
+        const float fx = __builtin_fmaf(hx.F, ax, bx), fy = __builtin_fmaf(hy.F, ay, by), fz = __builtin_fmaf(hz.F, az, bz);    \
+        const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);                                           \
+        const float tmax = fminf(fminf(fminf(fx, fy), fz), tv.best_t);                                      \
+        T = (tmin <= tmax) ? tmin : kInf;                                                                    \
     }
-    RT_WIDE_CHILD(t0, c0, x)
-    RT_WIDE_CHILD(t1, c1, y)
-    RT_WIDE_CHILD(t2, c2, z)
-    RT_WIDE_CHILD(t3, c3, w)
+    RT_WIDE_CHILD(t0, x)
+    RT_WIDE_CHILD(t1, y)
+    RT_WIDE_CHILD(t2, z)
+    RT_WIDE_CHILD(t3, w)
 #undef RT_WIDE_CHILD
-    const int n_hit = (int)(t0 < kInf) + (int)(t1 < kInf) + (int)(t2 < kInf) + (int)(t3 < kInf);
-    // nearest first (children not hit carry +inf and end up last)
+    // nearest first (children not hit carry +inf and end up last: the k-th entry is a hit iff its distance is finite)
 #define RT_WIDE_ORDER(TA, CA, TB, CB)                  \
     {                                                    \
         const bool swap = TB < TA;                       \
@@ -223,10 +226,10 @@ RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, con
     RT_WIDE_ORDER(t1, c1, t3, c3)
     RT_WIDE_ORDER(t1, c1, t2, c2)
 #undef RT_WIDE_ORDER
-    if (n_hit >= 4) { stack.put(tv.sp, (uint32_t)c3); tv.sp++; }
-    if (n_hit >= 3) { stack.put(tv.sp, (uint32_t)c2); tv.sp++; }
-    if (n_hit >= 2) { stack.put(tv.sp, (uint32_t)c1); tv.sp++; }
-    if (n_hit >= 1) tv.cur = c0;
+    if (t3 < kInf) { stack.put(tv.sp, (uint32_t)c3); tv.sp++; }
+    if (t2 < kInf) { stack.put(tv.sp, (uint32_t)c2); tv.sp++; }
+    if (t1 < kInf) { stack.put(tv.sp, (uint32_t)c1); tv.sp++; }
+    if (t0 < kInf) tv.cur = c0;
     else trav_pop(tv, stack);
 }
 

@@ -515,10 +515,21 @@ void collapse_wide(const HostBvh& bvh, HostWideBvh& out) {
         if (held > out.stack_need) out.stack_need = held;
         if (t.depth > out.depth) out.depth = t.depth;
         for (int k = 0; k < 4; ++k) {
-            if (k >= n) { w.child[k] = kWideUnused; continue; }
+            if (k >= n) {
+                w.child[k] = kWideUnused;
+                w.hx[k] = w.hy[k] = w.hz[k] = -1.0f;
+                continue;
+            }
             const WideRef& r = refs[(size_t)k];
-            w.lox[k] = r.lo[0]; w.loy[k] = r.lo[1]; w.loz[k] = r.lo[2];
-            w.hix[k] = r.hi[0]; w.hiy[k] = r.hi[1]; w.hiz[k] = r.hi[2];
+            float c[3], h[3];
+            for (int a = 0; a < 3; ++a) {
+                c[a] = 0.5f * r.lo[a] + 0.5f * r.hi[a];
+                const float need = std::fmax(r.hi[a] - c[a], c[a] - r.lo[a]);
+                h[a] = std::nextafter(std::nextafter(std::fmax(need, 0.0f), kInf), kInf);  // c - h <= lo and hi <= c + h as rounded sums too
+                while (c[a] - h[a] > r.lo[a] || c[a] + h[a] < r.hi[a]) h[a] = std::nextafter(h[a], kInf);
+            }
+            w.cx[k] = c[0]; w.cy[k] = c[1]; w.cz[k] = c[2];
+            w.hx[k] = h[0]; w.hy[k] = h[1]; w.hz[k] = h[2];
             if (r.count > 0) {
                 w.child[k] = (int32_t)(0x80000000u | ((uint32_t)(r.count - 1) << 28) | (uint32_t)r.child);
             } else {
@@ -558,8 +569,11 @@ bool validate_wide(const HostBvh& bvh, const HostWideBvh& wide, std::string* err
         depth = it.depth > depth ? it.depth : depth;
         for (int k = 0; k < 4; ++k) {
             const int32_t c = w.child[k];
-            if (c == kWideUnused) continue;
-            if (!(w.lox[k] <= w.hix[k] && w.loy[k] <= w.hiy[k] && w.loz[k] <= w.hiz[k])) return fail(err, "wide child box inverted");
+            if (c == kWideUnused) {
+                if (!(w.hx[k] < 0.0f && w.hy[k] < 0.0f && w.hz[k] < 0.0f)) return fail(err, "empty wide child can be entered");
+                continue;
+            }
+            if (!(w.hx[k] >= 0.0f && w.hy[k] >= 0.0f && w.hz[k] >= 0.0f)) return fail(err, "wide child box inverted");
             if (c < 0) {
                 const size_t first = (size_t)(c & 0x0fffffff);
                 const int32_t count = ((c >> 28) & 7) + 1;

@@ -72,13 +72,16 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_lea
 // first); levels <= 1 keeps the builder's depth-first order.  Same tree, same traversal, other addresses.
 void layout_treelets(HostBvh& bvh, int levels);
 
-// Four-wide form of the same tree for the pooled kernel: a node holds up to four children's boxes, one
-// component of all four per 16-byte load, and the children as the traversal's cursor words (an internal
+// Four-wide form of the same tree for the pooled kernel: a node holds up to four children's boxes as centre and
+// half extent (the slab test then needs no min / max per axis: entry = (c - o) / d - h / |d|, exit = ... + h / |d|),
+// one component of all four per 16-byte load, and the children as the traversal's cursor words (an internal
 // node's index; bit 31 | (count - 1) << 28 | first record for a leaf; kWideUnused for an empty place, whose
-// box is all zeros).  128 bytes: one cache line per visit, about half the visits of the binary tree.
+// half extent is negative: its entry lies behind its exit for every ray).  The half extents are rounded up, so a
+// box contains the binary tree's box it was made from.  128 bytes: one cache line per visit, about half the
+// visits of the binary tree.
 struct WideNode {
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
+    float cx[4], cy[4], cz[4];
+    float hx[4], hy[4], hz[4];
     int32_t child[4];
     int32_t pad[4];
 };
