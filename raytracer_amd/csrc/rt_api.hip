@@ -442,13 +442,13 @@ static int pooled_bvh_width(const RtContext* c, int overflow_words) {
     return c->opt.bvh_width != 0 ? c->opt.bvh_width : 4;
 }
 // Search steps of a pooled wave between two looks at the queues: about as many as a ray takes, so that few
-// lanes sit finished through the rest of a burst.  Four-wide tree, 1080p: the small scenes' rays take 7-8
-// steps (burst 16: 8.1 ms, 12: 7.8, 10: 7.76, 8: 7.76, 6: 8.1), the 1.07 M-triangle scene's 16 (burst 16: 13.25 ms,
-// 12: 13.3, 10: 13.4, 8: 13.6).
+// lanes sit finished through the rest of a burst.  Four-wide tree, 1080p: the small scenes' rays take 6 lane steps
+// in 7-8 wave steps (burst 6: 7.08 ms, 7: 7.00, 8: 7.01, 9: 7.07, 10: 7.11, 12: 7.28 on the teapot scene; 8 also
+// best at 4K and on the star scene), the 1.07 M-triangle scene's 16 (burst 12: 11.70 ms, 16: 11.70, 20: 11.69).
 static int pool_burst(const RtContext* c, int width) {
     if (c->opt.pool_burst > 0) return c->opt.pool_burst;
     const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
-    return (width == 4 && scene_bytes <= ((size_t)16 << 20)) ? 10 : 16;
+    return (width == 4 && scene_bytes <= ((size_t)16 << 20)) ? 8 : 16;
 }
 // Stack overflow words per lane the pooled kernel is given by rt_render_frame (which may allocate).
 static int pooled_overflow_words(const RtContext* c) {
