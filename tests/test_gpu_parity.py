@@ -409,6 +409,29 @@ def test_pooled_tree_widths_agree(ctx, teapot, kind):
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, 3)
 
 
+@pytest.mark.parametrize("kind", ["empty", "one_sphere", "one_triangle", "three"])
+def test_pooled_kernel_on_trees_of_a_single_node(ctx, kind):
+    """Scenes whose wide tree is one node with 0, 1 or 3 of its four places used: the pooled kernel must never enter
+    an empty place, and must agree with the oracle's flat loops bit for bit."""
+    from helpers import DEBUG_FLAGS
+    s = Scene(capi.RT_SCENE_EMPTY)
+    m = s.add_material((0.7, 0.6, 0.5, 1), (0, 0, 0, 0), (1, 1, 1, 0.5), (0, 0, 0, 0), 0.5, 0.0, 1.5, 0.0)
+    if kind in ("one_sphere", "three"):
+        s.add_sphere((0.0, 0.0, -3.0), 1.0, m)
+    if kind in ("one_triangle", "three"):
+        s.add_triangle((-2, -1, -4), (2, -1, -4), (0, 2, -4), m)
+    if kind == "three":
+        s.add_sphere((1.5, 0.5, -2.5), 0.4, m)
+        s.add_light((0.33, -0.67, -0.67, 0.0), (1, 1, 1, 3.0), capi.RT_LIGHT_DIRECTIONAL)
+    w = s.wide_bvh_info()
+    assert w["nodes"] == 1 and w["stack_need"] <= 2
+    W, H = 160, 120  # 19 200 pixels
+    o = oracle_frames(s, W, H, spp=2, max_bounces=3)
+    g = gpu_frames(ctx, s, W, H, spp=2, max_bounces=3, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+    assert g["stats"].pipeline == capi.RT_PIPELINE_POOLED and g["stats"].bvh_width == 4
+    assert_identical(g, o)
+
+
 @pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
 def test_full_size_frames_agree_across_pipelines(ctx, workload):
     """BASELINE.json's full sizes (C2: 1920x1080, 4 spp x 20 bounces on the star scene; C3: 1920x1080,

@@ -69,6 +69,35 @@ def test_noalloc_equals_render_frame_on_two_calls_the_second_smaller(flags):
         fb.close()
 
 
+def test_noalloc_on_a_scene_whose_wide_tree_outgrows_the_scratch_stack_area():
+    """The 1.07 M-triangle scene's four-wide tree can hold 43 traversal stack entries, the scratch array has room for 31
+    per lane: the no-allocation call walks the binary tree instead, rt_render_frame the wide one, and both must give
+    the same frame."""
+    from raytracer_amd.workloads import WORKLOADS, workload_camera
+    scene = Scene(WORKLOADS["c5"][0])
+    assert scene.wide_bvh_info()["stack_need"] > 31
+    ctx, fb = Context(0), Context(0)
+    try:
+        ctx.upload_scene(scene)
+        W, H = 320, 180
+        cam = workload_camera("c5", W, H)
+        flags = capi.RT_FLAG_POOLED
+        ctx.resize(W, H)
+        ctx.render_frame(cam, scene.push_constants(0.0, 0, True), make_params(2, 6, capi.RT_ACCEL_BVH, 0, 1, 0, flags))
+        want_acc, want_cnt = ctx.read_accum()
+        want_bgra, want_width = ctx.read_bgra8(), ctx.stats().bvh_width
+        fb.resize(W, H)
+        a, c, b = fb.device_buffers()
+        ctx.render_frame_noalloc(cam, scene.push_constants(0.0, 0, True), make_params(2, 6, capi.RT_ACCEL_BVH, 0, 1, 0, flags), a, c, b, W, H)
+        ctx.sync()
+        assert want_width == 4 and ctx.stats().bvh_width == 2
+        acc, cnt = fb.read_accum()
+        assert bit_equal_pixels(acc, want_acc).all() and np.array_equal(cnt, want_cnt) and np.array_equal(fb.read_bgra8(), want_bgra)
+    finally:
+        ctx.close()
+        fb.close()
+
+
 def test_noalloc_limits_are_refused_with_a_clear_error():
     scene = Scene(capi.RT_SCENE_CORNELL_STAR)
     ctx, fb = Context(0), Context(0)
