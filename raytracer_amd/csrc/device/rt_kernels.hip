@@ -24,7 +24,7 @@ namespace {
 // have finished (or none is left), so that finished lanes go on to shading and to their
 // next ray while the stragglers keep their cursor, stack and best hit and resume on the
 // next call: a long traversal no longer holds 63 idle lanes hostage.
-template <bool STATS>
+template <bool WIDE, bool STATS>
 RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack stack, Trav& tv, float t_occl, bool wants_result,
                             int exit_quota, uint32_t& n_nodes, uint32_t& n_tests, uint32_t& n_iters,
                             unsigned long long& wave_iters) {
@@ -39,13 +39,15 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack 
         if (STATS) wave_iters++;
         if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
             if (tv.cur >= 0 && tv.cur != kTravDone) {
-                trav_node_step(sc.nodes, sl, stack, tv);
+                if (WIDE) trav_wide_step(sc.nodes, sl, stack, tv);
+                else trav_node_step(sc.nodes, sl, stack, tv);
                 if (STATS) { n_nodes++; n_iters++; }
             }
         } else {
             if (tv.cur < 0) {
-                trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
-                if (STATS) { n_tests++; n_iters++; }
+                if (STATS) { n_tests += (WIDE && ((tv.cur >> 28) & 7) > 0) ? 2u : 1u; n_iters++; }
+                if (WIDE) trav_leaf_step2(sc.prims_bvh, ro, rd, stack, tv);  // the wide form comes with leaf pairs
+                else trav_leaf_step(sc.prims_bvh, ro, rd, stack, tv);
                 // a light-visibility ray is decided once something lies clearly in front of the light
                 if (tv.best_t < t_occl) tv.cur = kTravDone;
             }
@@ -60,10 +62,10 @@ enum { ST_IDLE = 0, ST_TRACE_PATH = 1, ST_TRACE_LIGHT = 2, ST_BOUNCE = 3 };
 
 template <int ACCEL, bool STATS>
 __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc, const FrameArgs fa) {
-    __shared__ uint32_t s_stack[(ACCEL == 1) ? (kStackDepth * kBlock) : 1];
+    __shared__ uint32_t s_stack[(ACCEL >= 1) ? (kStackDepth * kBlock) : 1];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const float4* __restrict__ recs = (ACCEL == 1) ? sc.prims_bvh : sc.prims_flat;
+    const float4* __restrict__ recs = (ACCEL >= 1) ? sc.prims_bvh : sc.prims_flat;
 
     // ---- per-lane path state
     int state = ST_IDLE;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
         if (state != ST_IDLE && fresh) {
             fresh = false;
             n_rays++;
-            tv.cur = (ACCEL == 1) ? 0 : kTravDone;  // node 0 is always an internal node
+            tv.cur = (ACCEL >= 1) ? 0 : kTravDone;  // node 0 is always an internal node
             tv.sp = 0;
             tv.best_t = kInf;
             tv.best_prio = 0x7fffffff;
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             // either way the comparison the shader makes comes out the same.  Not when the
             // per-pixel hash of nearest-hit ids is recorded, which needs the true nearest hit.
             t_occl = -kInf;
-            if (ACCEL == 1 && state == ST_TRACE_LIGHT && !(fa.flags & 2u)) {
+            if (ACCEL >= 1 && state == ST_TRACE_LIGHT && !(fa.flags & 2u)) {
                 if (__float_as_int(sc.lights[3 * s_light + 2].x) == 3 /* DIRECTIONAL */) {
                     t_occl = kInf;
                 } else {
@@ -192,17 +194,17 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                     tv.best_t = s_d + 0.2f;
                 }
             }
-            if (ACCEL != 1) {
+            if (ACCEL == 0) {
                 trace_flat(sc, qo, qd, tv.best_t, tv.best_idx);
                 if (STATS) n_tests += (uint32_t)sc.n_prims;
             }
         }
-        if (ACCEL == 1) {
+        if (ACCEL >= 1) {
             // leave the loop once half of the wave's busy lanes have a result to shade
             const int busy_lanes = __popcll(__ballot(state != ST_IDLE));
             int quota = (busy_lanes * fa.exit_quota_pct + 99) / 100;
             quota = quota < 1 ? 1 : quota;
-            trace_bvh_steps<STATS>(sc, qo, qd, LdsStack{&s_stack[tid]}, tv, t_occl, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
+            trace_bvh_steps<ACCEL == 2, STATS>(sc, qo, qd, LdsStack{&s_stack[tid]}, tv, t_occl, state != ST_IDLE, quota, n_nodes, n_tests, n_iters, wave_iters);
         }
         if (STATS) stamp2 = (long long)__builtin_readcyclecounter();
         // lanes whose search is still running keep their state and skip the continuation
@@ -521,6 +523,9 @@ hipError_t launch_persistent(K kernel, const DeviceScene& sc, const FrameArgs& f
 
 hipError_t launch_render(const DeviceScene& sc, const FrameArgs& fa, int accel, bool stats, int cu_count,
                          hipStream_t stream) {
+    if (accel == 2)
+        return stats ? launch_persistent(render_kernel<2, true>, sc, fa, cu_count, stream)
+                     : launch_persistent(render_kernel<2, false>, sc, fa, cu_count, stream);
     if (accel == 1)
         return stats ? launch_persistent(render_kernel<1, true>, sc, fa, cu_count, stream)
                      : launch_persistent(render_kernel<1, false>, sc, fa, cu_count, stream);

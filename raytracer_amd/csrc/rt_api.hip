@@ -479,8 +479,15 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
             RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c),
                                        c->stream));
         } else {
-            c->last_width = p.accel == RT_ACCEL_BVH ? 2 : 0;
-            RT_HIP(c, rtd::launch_render(sc_in, fa, p.accel, stats, c->cu_count, c->stream));
+            // the single kernel keeps a stack of rtd::kStackDepth entries per lane in LDS: the wide tree where that holds it
+            rtd::DeviceScene sc = sc_in;
+            int accel = p.accel;
+            if (accel == RT_ACCEL_BVH && c->wide_nodes > 0 && c->wide_stack_need < (int)rtd::kStackDepth && c->opt.bvh_width != 2) {
+                accel = 2;
+                sc.nodes = (const float4*)c->d_nodes_wide;
+            }
+            c->last_width = p.accel == RT_ACCEL_BVH ? (accel == 2 ? 4 : 2) : 0;
+            RT_HIP(c, rtd::launch_render(sc, fa, accel, stats, c->cu_count, c->stream));
         }
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));

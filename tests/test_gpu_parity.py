@@ -387,11 +387,12 @@ def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, st
     assert owned.any() and (a["counts"][owned] == 3).all()
 
 
+@pytest.mark.parametrize("pipeline", [capi.RT_FLAG_POOLED, capi.RT_FLAG_SINGLE_KERNEL])
 @pytest.mark.parametrize("kind", ["teapot", "mixed"])
-def test_pooled_tree_widths_agree(ctx, teapot, kind):
-    """The pooled kernel walks the four-wide form of the tree unless told otherwise (RT_OPT_BVH_WIDTH): both
-    widths hold the same leaves behind the same boxes, so they must agree bit for bit - with each other, and
-    (but for edge ties) with the oracle."""
+def test_tree_widths_agree(ctx, teapot, kind, pipeline):
+    """Both kernels walk the four-wide form of the tree unless told otherwise (RT_OPT_BVH_WIDTH) or its stack
+    does not fit: both widths hold the same leaves behind boxes that contain them, so they must agree bit for
+    bit - with each other, and (but for edge ties) with the oracle."""
     from helpers import DEBUG_FLAGS
     W, H = 120, 68
     s = teapot if kind == "teapot" else _custom_scene(kind)
@@ -400,7 +401,8 @@ def test_pooled_tree_widths_agree(ctx, teapot, kind):
     try:
         for width in (2, 4):
             ctx.set_option(capi.RT_OPT_BVH_WIDTH, width)
-            got[width] = gpu_frames(ctx, s, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+            got[width] = gpu_frames(ctx, s, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
+            assert got[width]["stats"].bvh_width == width
     finally:
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, 0)
     assert_identical(got[4], got[2])
