@@ -12,6 +12,7 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
 flags = {"pooled": capi.RT_FLAG_POOLED, "single": capi.RT_FLAG_SINGLE_KERNEL, "auto": 0}[mode]
 strip = tuple(int(v) for v in os.environ.get("RT_STRIP", "0,1,0").split(","))  # rows per strip, ranks, this rank
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
+spp = int(os.environ.get("RT_SPP", spp)); mb = int(os.environ.get("RT_BOUNCES", mb))  # overrides, for scaling studies
 s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
 ms = []
