@@ -15,10 +15,11 @@ namespace rtd {
 
 namespace {
 
-// Resumable nearest-hit search over the binary BVH (both child boxes in the parent; per-lane
-// stack in LDS: column `tid` of a [depth][block] array, lane-private, bank = tid mod 32 at
+// Resumable nearest-hit search over the tree - WIDE: its four-wide form, two primitives per leaf step; else the
+// binary one (both child boxes in the parent), one primitive per leaf step - with a per-lane
+// stack in LDS (column `tid` of a [depth][block] array, lane-private, bank = tid mod 32 at
 // every depth, so conflict-free).  Each loop iteration the wave votes (ballot + popcount)
-// for ONE kind of step — visit an internal node, or test one leaf primitive — and only the
+// for ONE kind of step — visit an internal node, or test a leaf's next primitive(s) — and only the
 // lanes whose cursor is of that kind take it; the minority waits a step instead of dragging
 // the whole wave through both code paths.  The loop returns as soon as `exit_quota` lanes
 // have finished (or none is left), so that finished lanes go on to shading and to their

@@ -12,11 +12,12 @@
 // next, and most vector instructions run with most lanes masked off; with one launch per
 // stage a 1080p frame has too few rays per launch to fill this chip.
 // Here a workgroup keeps kPool paths in flight for its lanes.  Slots that wait for the
-// same kind of work queue up in LDS (search, first-bounce result, later-bounce result, the
-// light's term, sample end, pixel end); a wave either
+// same kind of work queue up in LDS (search, first hit, later hit, miss, the light's term,
+// sample end, pixel end); a wave either
 //   * shades: pops 64 slots of ONE kind and runs that stage for all of them, or
-//   * searches: its lanes walk the BVH for 64 rays, and a lane whose ray has ended stores
-//     the result, queues the slot for its stage and pops the next waiting ray.
+//   * searches: its lanes walk the tree for 64 rays in bursts of steps - each step the wave votes for a
+//     visit of a (four-wide or binary) node or a test of the next two primitives of a leaf -, and a lane
+//     whose ray has ended stores the result, queues the slot for its stage and pops the next waiting ray.
 // Hot path state (RNG, pixel, counters, ray, attenuation, sample radiance, hash, hit: 72 B
 // per slot) lives in LDS, structure of arrays; what is touched once per sample or per
 // light query (pixel sum, light-query record: 64 B per slot) lives in device memory in a
