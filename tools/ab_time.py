@@ -13,6 +13,7 @@ flags = {"pooled": capi.RT_FLAG_POOLED, "single": capi.RT_FLAG_SINGLE_KERNEL, "a
 strip = tuple(int(v) for v in os.environ.get("RT_STRIP", "0,1,0").split(","))  # rows per strip, ranks, this rank
 preset, FW, FH, spp, mb, _ = WORKLOADS[name]
 spp = int(os.environ.get("RT_SPP", spp)); mb = int(os.environ.get("RT_BOUNCES", mb))  # overrides, for scaling studies
+FW = int(os.environ.get("RT_W", FW)); FH = int(os.environ.get("RT_H", FH))
 s = Scene(preset); ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 cam = workload_camera(name, FW, FH)
 ms = []
