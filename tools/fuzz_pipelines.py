@@ -40,7 +40,7 @@ for k in range(cases):
     scenes["random"] = random_scene(rng)
     name = rng.choice(list(scenes))
     s = scenes[name]
-    W, H = rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 130, 200]), rng.choice([1, 3, 8, 17, 40, 72, 129])
+    W, H = rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 130, 200, 333, 640]), rng.choice([1, 3, 8, 17, 40, 72, 129, 360])
     spp, mb, frames = rng.choice([1, 1, 2, 3, 5]), rng.choice([0, 1, 2, 4, 9, 20]), rng.choice([1, 2, 3])
     sky = rng.choice([0, 0, 1, 2, 3, 4])
     sc = rng.choice([1, 1, 2, 3])
