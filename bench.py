@@ -78,6 +78,9 @@ def main() -> None:
     ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled"],
                     help="schedule of the per-path program (same results): the library's own choice, the single "
                          "persistent kernel, or the pooled kernel (LDS queues)")
+    ap.add_argument("--frames-per-launch", type=int, default=1,
+                    help="single GPU: frames of the still camera handed to the library per step (rt_render_frames fuses up to 16 "
+                         "into one launch); the default, 1, is one rt_render_frame call per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
@@ -111,7 +114,8 @@ def main() -> None:
     ctx.bind_framebuffer(W, H, acc.data_ptr(), cnt.data_ptr(), bgra.data_ptr())
     cam = workload_camera(args.workload, W, H)
     partition = args.partition or ("samples" if args.workload == "c4" else "strips")
-    frames_per_step = FRAMES_PER_BATCH if partition == "samples" else 1
+    fpl = max(1, args.frames_per_launch) if not collective else 1
+    frames_per_step = FRAMES_PER_BATCH if partition == "samples" else fpl
     strip = (STRIP_ROWS, world, rank) if (collective and partition == "strips") else (0, 1, 0)
     pipe_flags = {"auto": 0, "single": capi.RT_FLAG_SINGLE_KERNEL, "pooled": capi.RT_FLAG_POOLED}[args.pipeline]
     params = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], pipe_flags)
@@ -132,8 +136,8 @@ def main() -> None:
             own = parallel.frames_of(FRAMES_PER_BATCH, world, rank)
             if ev is not None:
                 ev[0].record(rt_stream)
-            for i, f in enumerate(own):
-                ctx.render_frame(cam, scene.push_constants(0.0, frame * FRAMES_PER_BATCH + f, i == 0), params)
+            # (one call: the library fuses a rank's frames into one launch where that pays)
+            ctx.render_frames(cam, [scene.push_constants(0.0, frame * FRAMES_PER_BATCH + f, i == 0) for i, f in enumerate(own)], params)
             if ev is not None:
                 ev[1].record(rt_stream)
             if collective:
@@ -142,10 +146,13 @@ def main() -> None:
                 rt_stream.wait_stream(main_stream)
             ctx.resolve()
             return
-        pc = scene.push_constants(0.0, frame, frame == 0)
+        pc = scene.push_constants(0.0, frame * fpl, frame == 0)
         if ev is not None:
             ev[0].record(rt_stream)
-        ctx.render_frame(cam, pc, params)
+        if fpl > 1:
+            ctx.render_frames(cam, [scene.push_constants(0.0, frame * fpl + k, frame == 0 and k == 0) for k in range(fpl)], params)
+        else:
+            ctx.render_frame(cam, pc, params)
         if ev is not None:
             ev[1].record(rt_stream)
         if collective:
@@ -192,8 +199,8 @@ def main() -> None:
     fence()
     t1 = time.perf_counter()
     rays = ctx.stats().total_rays - rays0
-    own_frames = len(parallel.frames_of(FRAMES_PER_BATCH, world, rank)) if partition == "samples" else 1
-    kernel_ms = [a.elapsed_time(b) / max(1, own_frames) for a, b in events]  # per launch
+    own_frames = len(parallel.frames_of(FRAMES_PER_BATCH, world, rank)) if partition == "samples" else fpl
+    kernel_ms = [a.elapsed_time(b) / max(1, own_frames) for a, b in events]  # per frame (a launch may hold several)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
@@ -208,6 +215,7 @@ def main() -> None:
 
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
     pipeline = {capi.RT_PIPELINE_SINGLE: "single", capi.RT_PIPELINE_POOLED: "pooled"}[ctx.stats().pipeline]  # what the timed frames ran on
+    launch_frames = ctx.stats().frames  # frames the library put into the last timed launch
     flags = capi.RT_FLAG_TRAVERSAL_STATS | pipe_flags
     pc = scene.push_constants(0.0, SETTLE + args.warmup, False)
     ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
@@ -223,7 +231,7 @@ def main() -> None:
             rays_per_launch = job_rays / args.steps / FRAMES_PER_BATCH
         else:
             pixels_per_launch = W * H / world
-            rays_per_launch = job_rays / args.steps / world
+            rays_per_launch = job_rays / args.steps / world / fpl  # per frame of a launch of fpl frames
         if accel == capi.RT_ACCEL_BVH:
             # per ray: one box test (24 flop) per child of a visited node - 2 children in 64 B, or 4 in 128 B
             # (the pooled kernel's four-wide tree) -, 51 flop per triangle test; 48 B per tested primitive
@@ -279,7 +287,7 @@ def main() -> None:
                        "partition": ("single GPU" if not collective else
                                      f"row strips of {STRIP_ROWS} rows, one all-gather of packed colours + counts per frame" if partition == "strips" else
                                      f"frames of a {FRAMES_PER_BATCH}-frame batch dealt to ranks, all-reduce of accumulators"),
-                       "pipeline": pipeline, "frames_per_step": frames_per_step,
+                       "pipeline": pipeline, "frames_per_step": frames_per_step, "frames_per_launch": launch_frames,
                        "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},
             "roofline": {
                 "bound": "valu",

@@ -185,7 +185,8 @@ typedef struct RtStats {
                                search steps (the rest: handing results in, taking new rays)                      */
     int32_t  bvh_width;     /* children per node of the tree the last frame's kernel walked: 2, or 4 (pooled pipeline,
                                RT_OPT_BVH_WIDTH; nodes_visited then counts four-wide nodes); 0 for the flat loops   */
-    int32_t  reserved;
+    int32_t  frames;        /* frames the last launch rendered (rt_render_frames fuses up to 16; else 1); rays, the
+                               traversal counts and kernel_ms are that launch's                                    */
 } RtStats;
 
 typedef struct RtContext RtContext;
@@ -235,6 +236,16 @@ int rt_bind_framebuffer(RtContext* ctx, int32_t width, int32_t height,
  * rt_sync / rt_read_* / rt_get_stats as RT_ERR_HIP. */
 int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pc,
                     const RtParams* params);
+
+/* n_frames consecutive rt_render_frame calls with one camera and pcs[0 .. n_frames - 1], with the same result bit for
+ * bit - the reference's frame loop with a still camera (main.cpp:2160-2171: frameCount differs from frame to frame,
+ * the accumulation is reset at most by the first).  Where the frames differ in frameCount only and the pooled kernel
+ * applies (BVH search, no debug outputs, an image of at least 2 048 tiles), up to 16 frames at a time share ONE launch:
+ * a pixel's frames follow each other on one XCD, so the drain of one frame's last paths is hidden behind the next
+ * frame's first.  Otherwise the frames are rendered one by one.  RtStats then describe the last launch (rays: all its
+ * frames). */
+int rt_render_frames(RtContext* ctx, const RtCamera* camera, const RtPushConstants* pcs, int32_t n_frames,
+                     const RtParams* params);
 
 /* rt_render_frame for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same frame, same bits,

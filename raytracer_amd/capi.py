@@ -108,7 +108,7 @@ class RtStats(C.Structure):
                 ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
                 ("total_prims", C.c_int32), ("pipeline", C.c_int32),
                 ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64),
-                ("bvh_width", C.c_int32), ("reserved", C.c_int32)]
+                ("bvh_width", C.c_int32), ("frames", C.c_int32)]
 
 
 class RtSceneView(C.Structure):
@@ -148,6 +148,7 @@ PROTOTYPES = {
     "rt_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "rt_bind_framebuffer": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     "rt_render_frame": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams)]),
+    "rt_render_frames": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.c_int32, C.POINTER(RtParams)]),
     "rt_render_frame_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), _P, _P, _P,
                                           C.c_int32, C.c_int32]),
     "rt_resolve": (C.c_int, [_P]),
@@ -224,8 +225,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
     lib = C.CDLL(LIB_PATH)
+    older_build = "RT_LIB_PATH" in os.environ  # an A/B build of another revision (tools/ab_build.sh) may lack newer entry points
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if older_build:
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -62,7 +62,20 @@ struct FrameArgs {
     // segments traced for it this frame; the next frame's order is made from it.
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    // Several frames of one camera in one launch of the pooled kernel (n_frames > 1; up to kMaxBatchFrames): frame k
+    // is seeded with frame_counts[k], `reset` applies to frame 0.  The image blocks are shared out among the
+    // XCDs by their position in the order (position mod 8), the same in every frame of the launch, so that
+    // a pixel's frames follow each other on ONE XCD, whose L2 keeps them coherent (n_xcds: how many there are, probed
+    // once per device); xcd_next[32 * x] is XCD
+    // x's next slot (frame-major), block_done[b] counts the pixels of image block b finished so far
+    // (a frame's pixel ends after all the block's pixels of the frame before).  Both zeroed before the launch.
+    int32_t n_frames;
+    int32_t n_xcds;  // XCDs the launch's workgroups are spread over (their XCC_ID = 0 .. n_xcds - 1), <= kXcds
+    uint32_t frame_counts[16];
+    uint32_t* xcd_next;
+    uint32_t* block_done;
 };
+enum { kMaxBatchFrames = 16, kXcds = 8 };
 
 enum { kBlock = 256, kStackDepth = 32 };
 // Pixels are handed out in blocks of (1 << kBlockTilesLog2)^2 tiles of 8x8 pixels; the block is
@@ -104,6 +117,12 @@ int pool_threads_per_block();
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
                        int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream);
+// How many XCDs a grid of one workgroup per CU is spread over (the hardware's XCC_ID of every workgroup, read
+// back): their ids must be 0 .. n - 1, each with at least one workgroup; *n_xcds = 0 if that does not hold or
+// n > kXcds.  Synchronous; `scratch`: cu_count words of device memory.
+hipError_t probe_xcds(int cu_count, uint32_t* scratch, int* n_xcds, hipStream_t stream);
+// After a launch of several frames: sets *abort_flag (FrameArgs::abort_flag) unless every XCD handed out all its slots.
+hipError_t launch_batch_check(const FrameArgs& fa, hipStream_t stream);
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream);
 // Turns the per-tile costs of the frame just rendered into the next frame's tile order (most
 // expensive class first, image order within a class) and clears the costs.  At most

@@ -497,6 +497,49 @@ __global__ void __launch_bounds__(256) math_probe_kernel(int fn, const float* __
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(64) xcd_probe_kernel(uint32_t* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+// one thread: every XCD's slot counter must have passed the XCD's last slot (see take_pixels)
+__global__ void __launch_bounds__(64) batch_check_kernel(const uint32_t* xcd_next, uint32_t n_blocks, int n_xcds, int n_frames, uint32_t* abort_flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int x = 0; x < n_xcds; ++x) {
+        const uint32_t mine = n_blocks > (uint32_t)x ? (n_blocks - (uint32_t)x + (uint32_t)n_xcds - 1u) / (uint32_t)n_xcds : 0u;
+        if (xcd_next[32 * x] < (mine << kBlockSlotsLog2) * (uint32_t)n_frames) *(volatile uint32_t*)abort_flag = 1u;
+    }
+}
+}  // namespace
+
+hipError_t probe_xcds(int cu_count, uint32_t* scratch, int* n_xcds, hipStream_t stream) {
+    *n_xcds = 0;
+    if (cu_count < 1 || cu_count > 4096) return hipSuccess;
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3((unsigned)cu_count), dim3(64), 0, stream, scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t ids[4096];
+    e = hipMemcpyAsync(ids, scratch, (size_t)cu_count * 4, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    int seen[16] = {0}, top = -1;
+    for (int i = 0; i < cu_count; ++i) {
+        if (ids[i] > 15u) return hipSuccess;
+        seen[ids[i]]++;
+        top = (int)ids[i] > top ? (int)ids[i] : top;
+    }
+    for (int k = 0; k <= top; ++k)
+        if (seen[k] == 0) return hipSuccess;
+    if (top + 1 <= kXcds) *n_xcds = top + 1;
+    return hipSuccess;
+}
+
+hipError_t launch_batch_check(const FrameArgs& fa, hipStream_t stream) {
+    hipLaunchKernelGGL(batch_check_kernel, dim3(1), dim3(64), 0, stream, fa.xcd_next, fa.total_slots >> kBlockSlotsLog2, fa.n_xcds, fa.n_frames,
+                       fa.abort_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_math_probe(int fn, const float* x, const float* y, float* out, int n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, x, y, out, n);

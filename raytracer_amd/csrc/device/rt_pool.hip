@@ -114,6 +114,7 @@ struct PoolSlot {
     RT_DEV void put_col(V3 v) const { L.col[0][i] = v.x; L.col[1][i] = v.y; L.col[2][i] = v.z; }
     RT_DEV KernargFloats camera(const FrameArgs&) const { return kernarg_camera(); }  // pool_kernel(DeviceScene, FrameArgs, ...)
     RT_DEV FrameArgs late_frame(const FrameArgs&) const { return kernarg_frame(); }
+    RT_DEV uint32_t frame_count_of(uint32_t frame) const { return kernarg_frame_count(frame); }
     RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
     RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
     RT_DEV void put_hash(uint32_t phash) const { L.phash[i] = phash; }
@@ -249,9 +250,14 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
 // of the frame come from the workgroup's reserve, refilled kChunk at a time from the frame's
 // counter (one global atomic per kChunk pixels; the reserve is handed out under a small LDS
 // lock, taken a few hundred times per frame).  A slot that finds the frame exhausted dies.
+template <bool BATCH>
 RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, bool need, uint32_t local) {
     if (__ballot(need) == 0ull) return false;
     const FrameArgs fa = kernarg_frame();  // once per pixel: not worth scalar registers for the whole kernel
+    // a launch of several frames hands out the slots of this XCD (frame-major), a single frame those of the image
+    const bool batch = BATCH;
+    const uint32_t xcd = batch ? xcc_id() : 0u;
+    uint32_t* const counter = batch ? fa.xcd_next + 32u * xcd : fa.counters;
     bool started = false, dead = false;
     for (;;) {
         const unsigned long long m = __ballot(need);
@@ -268,7 +274,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
             c1 = avail < n ? avail : n;
             next += c1;
             if (c1 < n) {
-                b2 = atomicAdd(&fa.counters[0], kChunk);
+                b2 = atomicAdd(counter, kChunk);
                 next = b2 + (n - c1);
                 end = b2 + kChunk;
             }
@@ -284,11 +290,23 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
             const uint32_t rank = (uint32_t)__popcll(m & lanes_below());
             const uint32_t mine = rank < c1 ? b1 + rank : b2 + (rank - c1);
             int x, y;
-            if (mine >= fa.total_slots) {
+            if (batch) {
+                uint32_t frame, block;
+                bool exhausted;
+                if (batch_slot_to_pixel(fa, xcd, mine, x, y, frame, block, exhausted)) {
+                    start_pixel<BATCH>(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y, frame);
+                    need = false;
+                    started = true;
+                } else if (exhausted) {
+                    need = false;
+                    dead = true;
+                }
+                // else: a slot of a ragged edge block outside the image; ask again
+            } else if (mine >= fa.total_slots) {
                 need = false;
                 dead = true;
             } else if (slot_to_pixel(fa, mine, x, y)) {
-                start_pixel(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y);
+                start_pixel<BATCH>(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y);
                 need = false;
                 started = true;
             }
@@ -300,7 +318,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
     return started;  // the caller queues these slots for the search
 }
 
-template <int ACCEL, bool STATS>
+template <int ACCEL, bool STATS, bool BATCH>
 __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
                                                          int burst, int job_min, int slots_cap) {
     __shared__ PoolLds L;
@@ -319,13 +337,13 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     // only its share of slots (the rest stay dead), so that all CUs get work.
     // `slots_cap` (a multiple of the waves, at most kPool) limits the paths in flight further: a scene that
     // overflows the caches runs faster with fewer rays competing for them.
-    const uint32_t share = (fa.total_slots + gridDim.x - 1u) / gridDim.x;
+    const uint32_t share = (fa.total_slots * (uint32_t)(BATCH ? fa.n_frames : 1) + gridDim.x - 1u) / gridDim.x;
     const uint32_t per_wave = share >= (uint32_t)slots_cap ? (uint32_t)slots_cap / (uint32_t)kWaves : (share + kWaves - 1u) / kWaves;
     if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
         const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
-        queue_push(L, Q_SEARCH, take_pixels(L, fa, cold_base, g * 64u + (uint32_t)lane < per_wave, mine), mine);
+        queue_push(L, Q_SEARCH, take_pixels<BATCH>(L, fa, cold_base, g * 64u + (uint32_t)lane < per_wave, mine), mine);
     }
 
     // the ray this lane walks the BVH for
@@ -339,6 +357,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const bool hash_mode = (fa.flags & 2u) != 0u;
     const float occl_bias = hash_mode ? kInf : 0.2f;
     bool search_first = false;  // skip the look for shading work once
+    int pixel_hold = 0;         // rounds for which this wave leaves the pixel-end queue alone (see there)
     // Where a sample goes when path and light query have both ended: to the light's term if the light is
     // visible (`flags` as they were when the later of the two ended), else to the pixel's end after its last
     // sample, else to the next sample.
@@ -364,7 +383,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         if (ctl.count[Q_FIRST] > best) { best = ctl.count[Q_FIRST]; q = Q_FIRST; }
         if (ctl.count[Q_END] > best) { best = ctl.count[Q_END]; q = Q_END; }
         if (ctl.count[Q_LIT] > best) { best = ctl.count[Q_LIT]; q = Q_LIT; }
-        if (ctl.count[Q_PIXEL] > best) { best = ctl.count[Q_PIXEL]; q = Q_PIXEL; }
+        if (ctl.count[Q_PIXEL] > best && (!BATCH || pixel_hold == 0)) { best = ctl.count[Q_PIXEL]; q = Q_PIXEL; }
+        if (BATCH && pixel_hold > 0) pixel_hold--;
         if (ctl.count[Q_MISS] > best) { best = ctl.count[Q_MISS]; q = Q_MISS; }
         const unsigned long long busy = __ballot(slot >= 0);
         const bool nothing_to_search = (busy == 0ull) && ctl.count[Q_SEARCH] == 0u;
@@ -384,9 +404,16 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             const uint32_t i = item & 0xfffu;
             const PoolSlot ps{L, cold_base + 4 * i, i};
             if (q == Q_PIXEL) {
-                if (got) end_pixel_item(fa, ps);
-                const bool started = take_pixels(L, fa, cold_base, got, i);
+                // (in a launch of several frames a pixel may have to wait for its previous frame's store: back into the queue)
+                const bool ended = got && end_pixel_item<BATCH>(fa, ps);
+                const bool started = take_pixels<BATCH>(L, fa, cold_base, ended, i);
                 queue_push(L, Q_SEARCH, started, i);  // kind 0: the next pixel's first ray
+                if (BATCH) {
+                    queue_push(L, Q_PIXEL, got && !ended, i);
+                    // the pixels that wait must not keep this wave from the other queues (the fullest queue is served
+                    // first, and a queue of waiting pixels stays full): it looks away from this one for a while
+                    if (__ballot(got && !ended) != 0ull) { search_first = true; pixel_hold = 16; }
+                }
             } else if (q == Q_END) {
                 if (got) end_sample_item(fa, ps);
                 queue_push(L, Q_SEARCH, got, i);  // kind 0: the next sample's first ray
@@ -561,10 +588,12 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
 }
 
 typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int);
-PoolKernel pick_kernel(int accel, bool stats) {
-    if (accel == 2) return stats ? pool_kernel<2, true> : pool_kernel<2, false>;
-    return accel == 1 ? (stats ? pool_kernel<1, true> : pool_kernel<1, false>) : (stats ? pool_kernel<0, true> : pool_kernel<0, false>);
+template <bool BATCH>
+PoolKernel pick_kernel_of(int accel, bool stats) {
+    if (accel == 2) return stats ? pool_kernel<2, true, BATCH> : pool_kernel<2, false, BATCH>;
+    return accel == 1 ? (stats ? pool_kernel<1, true, BATCH> : pool_kernel<1, false, BATCH>) : (stats ? pool_kernel<0, true, BATCH> : pool_kernel<0, false, BATCH>);
 }
+PoolKernel pick_kernel(int accel, bool stats, bool batch = false) { return batch ? pick_kernel_of<true>(accel, stats) : pick_kernel_of<false>(accel, stats); }
 constexpr size_t kStackLds = (size_t)kShortStack * kThreads * sizeof(uint32_t);
 
 }  // namespace
@@ -593,7 +622,7 @@ hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPoo
                        int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
     slots_cap = (slots_cap <= 0 || slots_cap > kPool) ? kPool : (slots_cap < kWaves ? kWaves : slots_cap / kWaves * kWaves);
-    hipLaunchKernelGGL(pick_kernel(accel, stats), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap);
+    hipLaunchKernelGGL(pick_kernel(accel, stats, fa.n_frames > 1), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap);
     return hipGetLastError();
 }
 

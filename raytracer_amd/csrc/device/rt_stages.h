@@ -17,6 +17,7 @@ RT_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 // that handles the first hit picks the light, notes what the term needs, sends off the visibility ray
 // and the bounce ray together, and the sample's end evaluates the term if the light proved visible.
 // Per-slot flag bits:
+enum : uint32_t { kPixelFrameShift = 28, kPixelIndexMask = (1u << 28) - 1u };  // a slot's pixel word: index | frame of the launch << 28
 enum : uint32_t {
     LF_PENDING = 1u,   // this sample has a light query in flight or finished
     LF_DONE = 2u,      // its search has ended
@@ -118,7 +119,7 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
     }
     if (kind == 0) {
         sl.put_flags(flags);
-        if (sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel] = prim_id;
+        if (sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel & kPixelIndexMask] = prim_id;
     }
     phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
@@ -174,7 +175,8 @@ RT_DEV V3 lit_term(const DeviceScene& sc, const Slot& sl) {
 // First primary ray of a sample (get_ray, raytracer.comp:933-952) into the slot.
 template <typename Slot>
 RT_DEV void start_sample(const FrameArgs& fa, const Slot& sl, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t phash) {
-    const int px = (int)(pixel % (uint32_t)fa.width), py = (int)(pixel / (uint32_t)fa.width);
+    const uint32_t index = pixel & kPixelIndexMask;  // (the frame of a multi-frame launch rides in the top bits)
+    const int px = (int)(index % (uint32_t)fa.width), py = (int)(index / (uint32_t)fa.width);
     V3 ro, rd;
     generate_ray(fa, sl.camera(fa), px, py, seed, ro, rd);
     sl.put_ctl(seed, pixel, sample, 0);
@@ -218,21 +220,39 @@ RT_DEV void end_sample_item(const FrameArgs& fa, const Slot& sl) {
     start_sample(fa, sl, seed, pixel, sample + 1u, phash);
 }
 
-// The pixel's last sample ends: gamma, accumulation and rgba8 store (raytracer.comp:978-995).
-template <typename Slot>
-RT_DEV void end_pixel_item(const FrameArgs& fa, const Slot& sl) {
-    uint32_t seed, pixel, sample, phash;
+// The pixel's last sample ends: gamma, accumulation and rgba8 store (raytracer.comp:978-995).  False: not yet -
+// in a launch of several frames the pixel's previous frame has not been stored; the caller asks again later.
+template <bool BATCH, typename Slot>
+RT_DEV bool end_pixel_item(const FrameArgs& fa, const Slot& sl) {
+    uint32_t seed, pixel_word, sample, phash;
     int bounce;
-    sl.get_ctl(seed, pixel, sample, bounce);
+    sl.get_ctl(seed, pixel_word, sample, bounce);
+    const uint32_t pixel = pixel_word & kPixelIndexMask, frame = pixel_word >> kPixelFrameShift;
+    const auto& ff = sl.late_frame(fa);  // the frame's arguments, possibly loaded only here
+    const int py = (int)(pixel / (uint32_t)ff.width), px = (int)pixel - py * ff.width;
+    const bool batch = BATCH;  // (a launch of several frames runs the kernel compiled for it: the other pays nothing for this)
+    uint32_t block = 0;
+    if (batch) {
+        // frame k of a pixel follows frame k - 1 of all the pixels of its image block (same XCD: see FrameArgs)
+        uint32_t inside;
+        block = block_of_pixel(ff, px, py, inside);
+        if (frame != 0u && l2_load(&ff.block_done[block]) < frame * inside) return false;
+    }
     float cost;
     const V3 pix = end_of_sample(fa, sl, bounce, cost, phash);
-    const auto& ff = sl.late_frame(fa);  // the frame's arguments, possibly loaded only here
     V3 cc = g_pow(pix / (float)ff.spp, 1.0f / 2.2f);
     float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int n = 0;
-    if (!ff.reset) {
-        a = ff.accum[pixel];
-        n = ff.counts[pixel];
+    if (!(ff.reset && frame == 0u)) {
+        if (batch) {  // what another CU of this XCD may have stored a moment ago: read where it was written to
+            const uint32_t* w = (const uint32_t*)&ff.accum[pixel];
+            a = make_float4(__uint_as_float(l2_load(w + 0)), __uint_as_float(l2_load(w + 1)), __uint_as_float(l2_load(w + 2)),
+                            __uint_as_float(l2_load(w + 3)));
+            n = (int)l2_load((const uint32_t*)&ff.counts[pixel]);
+        } else {
+            a = ff.accum[pixel];
+            n = ff.counts[pixel];
+        }
     }
     a.x += cc.x; a.y += cc.y; a.z += cc.z; a.w += 1.0f;
     n += 1;
@@ -240,16 +260,21 @@ RT_DEV void end_pixel_item(const FrameArgs& fa, const Slot& sl) {
     ff.counts[pixel] = n;
     ff.bgra[pixel] = resolve_pixel(a, n);
     if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
-    const int py = (int)(pixel / (uint32_t)ff.width);
-    report_pixel_cost(ff, (int)pixel - py * ff.width, py, (uint32_t)cost);
+    report_pixel_cost(ff, px, py, (uint32_t)cost);
+    if (batch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached the L2 before the block's count says so
+        (void)l2_add(&ff.block_done[block], 1u);
+    }
+    return true;
 }
 
-// A slot's first sample of pixel (x, y): seed (raytracer.comp:959-961), empty pixel sum.
-template <typename Slot>
-RT_DEV void start_pixel(const FrameArgs& fa, const Slot& sl, int x, int y) {
-    const uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(fa.frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
+// A slot's first sample of pixel (x, y) in frame `frame` of the launch: seed (raytracer.comp:959-961), empty pixel sum.
+template <bool BATCH, typename Slot>
+RT_DEV void start_pixel(const FrameArgs& fa, const Slot& sl, int x, int y, uint32_t frame = 0u) {
+    const uint32_t frame_count = BATCH ? sl.frame_count_of(frame) : fa.frame_count;
+    const uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
     sl.put_pix(v3(0.0f), 0.0f);
-    start_sample(fa, sl, seed, (uint32_t)(y * fa.width + x), 0u, 0u);
+    start_sample(fa, sl, seed, (uint32_t)(y * fa.width + x) | (frame << kPixelFrameShift), 0u, 0u);
 }
 
 }  // namespace rtd

@@ -321,6 +321,19 @@ RT_DEV FrameArgs kernarg_frame() {
 #endif
 }
 
+// FrameArgs::frame_counts[frame] read from the kernel-argument segment (indexing a by-value copy of the block by a
+// lane's frame would put the whole copy into scratch memory).  Same kernels as kernarg_camera.
+RT_DEV uint32_t kernarg_frame_count(uint32_t frame) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    p += ((sizeof(DeviceScene) + alignof(FrameArgs) - 1) & ~(alignof(FrameArgs) - 1)) + offsetof(FrameArgs, frame_counts);
+    return ((const __attribute__((address_space(4))) uint32_t*)p)[frame];
+#else
+    return frame;
+#endif
+}
+
 // get_ray, raytracer.comp:933-952: jittered primary ray through pixel (px, py); `cam` = the camera block.
 template <typename CamPtr>
 RT_DEV void generate_ray(const FrameArgs& fa, CamPtr cam, int px, int py, uint32_t& seed, V3& ro, V3& rd) {
@@ -357,6 +370,56 @@ RT_DEV bool slot_to_pixel(const FrameArgs& fa, uint32_t slot, int& x, int& y) {
     if (fa.strip_rows > 0) y = ((r / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (r % fa.strip_rows);
     return true;
 }
+
+// The same for a launch of several frames (FrameArgs::n_frames): slot `slot` of XCD `xcd`, frame-major; the XCD's
+// blocks are those at positions xcd, xcd + n_xcds, ... of the order.  `frame` and the image block are returned
+// also for a slot outside the image (false), which the caller reports as finished.  `exhausted`: the XCD has
+// no such slot.
+RT_DEV bool batch_slot_to_pixel(const FrameArgs& fa, uint32_t xcd, uint32_t slot, int& x, int& y, uint32_t& frame, uint32_t& block,
+                                bool& exhausted) {
+    const uint32_t n_blocks = fa.total_slots >> kBlockSlotsLog2;
+    const uint32_t nx = (uint32_t)fa.n_xcds;
+    const uint32_t mine = n_blocks > xcd ? (n_blocks - xcd + nx - 1u) / nx : 0u;
+    const uint32_t per_frame = mine << kBlockSlotsLog2;
+    exhausted = per_frame == 0u || slot >= per_frame * (uint32_t)fa.n_frames;
+    frame = 0; block = 0;
+    if (exhausted) return false;
+    frame = slot / per_frame;
+    const uint32_t r = slot - frame * per_frame;
+    const uint32_t pos = xcd + (r >> kBlockSlotsLog2) * nx;
+    block = fa.tile_order != nullptr ? fa.tile_order[pos] : pos;
+    const uint32_t in = r & ((1u << kBlockSlotsLog2) - 1u);
+    const uint32_t tile = in >> 6, p = in & 63u;
+    const uint32_t tmask = (1u << kBlockTilesLog2) - 1u;
+    x = (int)(((block % (uint32_t)fa.tiles_x) << kBlockPixLog2) + ((tile & tmask) << 3) + (p & 7u));
+    const int rr = (int)(((block / (uint32_t)fa.tiles_x) << kBlockPixLog2) + ((tile >> kBlockTilesLog2) << 3) + (p >> 3));
+    if (x >= fa.width || rr >= fa.owned_rows) return false;
+    y = rr;
+    if (fa.strip_rows > 0) y = ((rr / fa.strip_rows) * fa.strip_count + fa.strip_index) * fa.strip_rows + (rr % fa.strip_rows);
+    return true;
+}
+RT_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }  // hwreg XCC_ID, bits 3:0
+// Image block of pixel (x, y), as report_pixel_cost and FrameArgs::block_done index it, and how many of the block's
+// pixel slots lie inside the image (the rows this context owns).
+RT_DEV uint32_t block_of_pixel(const FrameArgs& fa, int x, int y, uint32_t& pixels_inside) {
+    int r = y;
+    if (fa.strip_rows > 0) r = ((y / fa.strip_rows) / fa.strip_count) * fa.strip_rows + (y % fa.strip_rows);
+    const int side = 1 << kBlockPixLog2;
+    const int bx = x >> kBlockPixLog2, by = r >> kBlockPixLog2;
+    const int w = fa.width - bx * side, h = fa.owned_rows - by * side;
+    pixels_inside = (uint32_t)((w < side ? w : side) * (h < side ? h : side));
+    return (uint32_t)by * (uint32_t)fa.tiles_x + (uint32_t)bx;
+}
+// Accesses that are performed in the XCD's L2 (atomics never hit the L1; workgroup scope keeps them out of the
+// memory-side path): how a pixel's frames, rendered by different CUs of one XCD, see each other's framebuffer values.
+// (The load is an atomic add of a zero the compiler cannot see through: it turns an atomic OR / ADD of a literal 0 into a
+// plain load, which may hit the L1 - for ever, when the value is being waited for.)
+RT_DEV uint32_t l2_load(const uint32_t* p) {
+    uint32_t zero = 0u;
+    asm volatile("" : "+v"(zero));
+    return __hip_atomic_fetch_add((uint32_t*)p, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+RT_DEV uint32_t l2_add(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // A finished pixel reports what it cost (path segments over all its samples) to its image block,
 // which keeps the largest: a block is as urgent as its longest pixel, because the frame cannot

@@ -26,10 +26,12 @@ struct RtOptions {
 struct RtContext {
     int device = 0;
     int cu_count = 0;
+    int n_xcds = 0;  // XCDs the device's workgroups are spread over (0: unknown, several frames are never fused into one launch)
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
     int32_t last_pipeline = 0;
+    int32_t last_frames = 1;  // frames rendered by the last launch (rt_render_frames)
     int32_t last_width = 0;  // children per node of the tree the last frame's kernel walked (0: the flat loops)
     RtOptions opt;
 
@@ -60,6 +62,8 @@ struct RtContext {
     uint32_t* d_tile_order = nullptr;
     uint32_t* d_tile_cost = nullptr;
     uint32_t* d_tile_aux = nullptr;  // work area of the tile order kernels
+    uint32_t* d_batch = nullptr;     // several frames in one launch: per-XCD slot counters and per-block finished counts
+    size_t batch_words = 0;
     uint32_t tile_capacity = 0;
     bool order_ready = false;                   // d_tile_order holds the order made from the last frame
     int32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // width, height, strip_rows, strip_count, strip_index, tiles it was made for

@@ -272,6 +272,12 @@ class Context:
         self._chk(self._lib.rt_render_frame(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None),
                   "rt_render_frame")
 
+    def render_frames(self, camera: capi.RtCamera, pcs, params: Optional[capi.RtParams] = None):
+        """Consecutive frames of one camera (pcs: a sequence of RtPushConstants), fused into one launch where possible."""
+        arr = (capi.RtPushConstants * len(pcs))(*pcs)
+        self._chk(self._lib.rt_render_frames(self._h, C.byref(camera), arr, len(pcs), C.byref(params) if params else None),
+                  "rt_render_frames")
+
     def render_frame_noalloc(self, camera, pc, params, accum_ptr: int, counts_ptr: int, bgra_ptr: int, width: int, height: int):
         self._chk(self._lib.rt_render_frame_noalloc(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None,
                                                     C.c_void_p(accum_ptr), C.c_void_p(counts_ptr), C.c_void_p(bgra_ptr),
