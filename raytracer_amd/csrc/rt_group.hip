@@ -289,6 +289,29 @@ int rt_group_resize(RtGroup* g, int32_t width, int32_t height) {
     return RT_OK;
 }
 
+int rt_group_render_frames(RtGroup* g, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int32_t frames_per_device) {
+    if (!g || !camera || !pc) return RT_ERR_INVALID_ARGUMENT;
+    if (frames_per_device < 1 || frames_per_device > 4096) return gfail(g, RT_ERR_INVALID_ARGUMENT, "frames_per_device out of range");
+    const int n = (int)g->ctx.size();
+    RtParams p;
+    if (params) p = *params; else rt_default_params(&p);
+    p.strip_rows = 0; p.strip_count = 1; p.strip_index = 0;
+    // device i renders the frames numbered frameCount + i, + i + n, ...: what frames_per_device calls of
+    // rt_group_render_frame(RT_GROUP_SAMPLES) with frameCount advanced by n each time give, but every device gets
+    // its frames in one rt_render_frames call (one launch where that applies); pc's reset applies to a device's first
+    std::vector<RtPushConstants> pcs((size_t)frames_per_device);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < frames_per_device; ++k) {
+            pcs[(size_t)k] = *pc;
+            pcs[(size_t)k].frameCount = pc->frameCount + (uint32_t)(i + k * n);
+            if (k > 0) pcs[(size_t)k].reset_frame_accumulation = 0;
+        }
+        int rc = rt_render_frames(g->ctx[(size_t)i], camera, pcs.data(), frames_per_device, &p);
+        if (rc != RT_OK) return gfail(g, rc, rt_last_error(g->ctx[(size_t)i]));
+    }
+    return RT_OK;
+}
+
 int rt_group_render_frame(RtGroup* g, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int mode,
                           int32_t strip_rows) {
     if (!g || !camera || !pc) return RT_ERR_INVALID_ARGUMENT;
