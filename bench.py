@@ -3,11 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one frame (one execution of the reference shader's main() per pixel) of the
-workload BASELINE.json's metric is quoted on: Cornell box + teapot.glb, 1920x1080, 16
-samples per pixel, 4 bounces.  At N > 1 (launched by torch.distributed.run, one rank per
-GPU) the frame is split into row strips, the scene is replicated, and the frame is
-completed on every rank by an RCCL all-gather; the total work is fixed, so scaling is
+One step = --frames-per-launch frames (8 unless told otherwise; a frame = one execution of the reference
+shader's main() per pixel) of the workload BASELINE.json's metric is quoted on: Cornell box + teapot.glb,
+1920x1080, 16 samples per pixel, 4 bounces, still camera, frameCount advancing from frame to frame as in the
+reference's frame loop.  The frames of a step are handed to the library in one rt_render_frames call, which
+fuses them into one launch; `value` is rays per second over all of it, `ms_per_frame` the step's time divided
+by its frames, and `ms_single_frame_launch` what one frame costs launched alone (--frames-per-launch 1 makes
+that the step).  At N > 1 (launched by torch.distributed.run, one rank per GPU) each frame is split into row
+strips, the scene is replicated, and the accumulated frame is completed on every rank by one RCCL all-gather
+per step; the total work is fixed, so scaling is
 "strong".  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
@@ -78,9 +82,10 @@ def main() -> None:
     ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled"],
                     help="schedule of the per-path program (same results): the library's own choice, the single "
                          "persistent kernel, or the pooled kernel (LDS queues)")
-    ap.add_argument("--frames-per-launch", type=int, default=1,
-                    help="single GPU: frames of the still camera handed to the library per step (rt_render_frames fuses up to 16 "
-                         "into one launch); the default, 1, is one rt_render_frame call per step")
+    ap.add_argument("--frames-per-launch", type=int, default=8,
+                    help="row-strip / single-GPU runs: frames of the still camera handed to the library per step (rt_render_frames "
+                         "fuses up to 16 into one launch; with several ranks the strips are exchanged once per step); "
+                         "1 = one rt_render_frame call (and one exchange) per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
@@ -114,7 +119,7 @@ def main() -> None:
     ctx.bind_framebuffer(W, H, acc.data_ptr(), cnt.data_ptr(), bgra.data_ptr())
     cam = workload_camera(args.workload, W, H)
     partition = args.partition or ("samples" if args.workload == "c4" else "strips")
-    fpl = max(1, args.frames_per_launch) if not collective else 1
+    fpl = max(1, args.frames_per_launch)
     frames_per_step = FRAMES_PER_BATCH if partition == "samples" else fpl
     strip = (STRIP_ROWS, world, rank) if (collective and partition == "strips") else (0, 1, 0)
     pipe_flags = {"auto": 0, "single": capi.RT_FLAG_SINGLE_KERNEL, "pooled": capi.RT_FLAG_POOLED}[args.pipeline]
@@ -216,6 +221,17 @@ def main() -> None:
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
     pipeline = {capi.RT_PIPELINE_SINGLE: "single", capi.RT_PIPELINE_POOLED: "pooled"}[ctx.stats().pipeline]  # what the timed frames ran on
     launch_frames = ctx.stats().frames  # frames the library put into the last timed launch
+    # what ONE frame costs when it is launched alone (the latency of a frame, where the steps above measure throughput):
+    # kernel time of single rt_render_frame calls on this rank's rows, median of five
+    single_ms = []
+    for k in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(rt_stream)
+        ctx.render_frame(cam, scene.push_constants(0.0, 100000 + k, False), params)
+        b.record(rt_stream)
+        ctx.sync()
+        single_ms.append(a.elapsed_time(b))
+    single_frame_ms = sorted(single_ms)[len(single_ms) // 2]
     flags = capi.RT_FLAG_TRAVERSAL_STATS | pipe_flags
     pc = scene.push_constants(0.0, SETTLE + args.warmup, False)
     ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
@@ -278,6 +294,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
             "ms_per_frame": elapsed_s / args.steps / frames_per_step * 1e3,
+            "ms_single_frame_launch": single_frame_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -285,7 +302,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "search": args.accel,
                        "partition": ("single GPU" if not collective else
-                                     f"row strips of {STRIP_ROWS} rows, one all-gather of packed colours + counts per frame" if partition == "strips" else
+                                     f"row strips of {STRIP_ROWS} rows, one all-gather of packed colours + counts per step of {fpl} frame(s)" if partition == "strips" else
                                      f"frames of a {FRAMES_PER_BATCH}-frame batch dealt to ranks, all-reduce of accumulators"),
                        "pipeline": pipeline, "frames_per_step": frames_per_step, "frames_per_launch": launch_frames,
                        "rays_per_step": job_rays / args.steps, "ray_definition": "1 ray = 1 nearest-hit search"},

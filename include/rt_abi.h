@@ -347,12 +347,15 @@ int rt_group_resize(RtGroup* grp, int32_t width, int32_t height);
  * Asynchronous on the contexts' streams. */
 int rt_group_render_frame(RtGroup* grp, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params,
                           int mode, int32_t strip_rows);
-/* RT_GROUP_SAMPLES for a longer batch: device i renders the frames numbered frameCount + i, + i + n, ... (frames_per_device
- * of them) into its own accumulator - the same frames and results as frames_per_device calls of rt_group_render_frame
- * with frameCount advanced by n each time, but handed to each device in one rt_render_frames call (one launch where
- * that applies).  pc->reset_frame_accumulation applies to every device's first frame. */
-int rt_group_render_frames(RtGroup* grp, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params,
-                           int32_t frames_per_device);
+/* `frames` frames of a still camera per call.  RT_GROUP_STRIPS: the frames numbered frameCount, frameCount + 1, ...; every
+ * device renders its strips of all of them (one rt_render_frames call: one launch where that applies) and the
+ * accumulated frame is completed everywhere by ONE all-gather - the result of `frames` rt_group_render_frame calls, bit for
+ * bit, for one exchange instead of `frames`, and with a device's share of frame k + 1 filling the drain of its share of
+ * frame k.  RT_GROUP_SAMPLES: device i renders the frames numbered frameCount + i, + i + n, ... into its own accumulator,
+ * as `frames` calls with frameCount advanced by n each time.  pc->reset_frame_accumulation applies to the first frame
+ * (of every device). */
+int rt_group_render_frames(RtGroup* grp, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int mode,
+                           int32_t strip_rows, int32_t frames);
 /* Sum of all devices' accumulated colours and counts on device 0 (one ncclReduce each) and its BGRA8 image
  * in context 0's output; the devices' own accumulators are left as they are, so a progressive
  * rendering can go on and be reduced again.  Float sums run in the reduction's order, not in frame

@@ -161,7 +161,7 @@ PROTOTYPES = {
     "rt_group_context": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rt_group_upload_scene_from": (C.c_int, [_P, _P]),
     "rt_group_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
-    "rt_group_render_frames": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), C.c_int32]),
+    "rt_group_render_frames": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), C.c_int, C.c_int32, C.c_int32]),
     "rt_group_render_frame": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtPushConstants), C.POINTER(RtParams), C.c_int, C.c_int32]),
     "rt_group_reduce_samples": (C.c_int, [_P]),
     "rt_group_read_total": (C.c_int, [_P, _P, _P]),

@@ -289,24 +289,81 @@ int rt_group_resize(RtGroup* g, int32_t width, int32_t height) {
     return RT_OK;
 }
 
-int rt_group_render_frames(RtGroup* g, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int32_t frames_per_device) {
+// `n_frames` frames (pcs[0 .. n_frames - 1]) shared by row strips: every device renders its rows of all of them with
+// global pixel coordinates (the bits of one-GPU frames) - in one rt_render_frames call -, packs its accumulated rows,
+// and one all-gather completes the accumulated frame everywhere.
+static int render_strips(RtGroup* g, const RtCamera* camera, const RtPushConstants* pcs, int n_frames, RtParams p, int32_t strip_rows) {
+    const int n = (int)g->ctx.size();
+    if (strip_rows <= 0) return gfail(g, RT_ERR_INVALID_ARGUMENT, "strip_rows must be positive");
+    const int32_t w = g->ctx[0]->width, h = g->ctx[0]->height;
+    if (w <= 0 || h <= 0) return gfail(g, RT_ERR_NO_FRAMEBUFFER, "rt_group_resize has not been called");
+    const int32_t key[4] = {w, h, strip_rows, n};
+    if (memcmp(key, g->stage_key, sizeof key) != 0) {
+        free_group_buffers(g);
+        g->staging_bytes = rt_strip_staging_bytes(w, h, strip_rows, n);
+        for (int i = 0; i < n; ++i) {
+            RT_GHIP(g, hipSetDevice(g->ctx[(size_t)i]->device));
+            RT_GHIP(g, hipStreamSynchronize(g->ctx[(size_t)i]->stream));
+            RT_GHIP(g, hipMalloc(&g->staging[(size_t)i], g->staging_bytes));
+            RT_GHIP(g, hipMalloc(&g->gathered[(size_t)i], g->staging_bytes * (size_t)n));
+            RT_GHIP(g, hipMemsetAsync(g->staging[(size_t)i], 0, g->staging_bytes, g->ctx[(size_t)i]->stream));
+        }
+        memcpy(g->stage_key, key, sizeof key);
+    }
+    for (int i = 0; i < n; ++i) {
+        RtContext* c = g->ctx[(size_t)i];
+        p.strip_rows = strip_rows; p.strip_count = n; p.strip_index = i;
+        int rc = n_frames == 1 ? rt_render_frame(c, camera, pcs, &p) : rt_render_frames(c, camera, pcs, n_frames, &p);
+        if (rc == RT_OK) rc = rt_strip_pack(c, strip_rows, n, i, g->staging[(size_t)i]);
+        if (rc != RT_OK) return gfail(g, rc, rt_last_error(c));
+    }
+    Rccl& r = rccl();
+    RT_GNCCL(g, r.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        ncclResult_t nr = r.AllGather(g->staging[(size_t)i], g->gathered[(size_t)i], g->staging_bytes, ncclChar, g->comm[(size_t)i],
+                                      g->ctx[(size_t)i]->stream);
+        if (nr != ncclSuccess) {
+            (void)r.GroupEnd();
+            return gfail(g, RT_ERR_HIP, std::string("ncclAllGather: ") + r.GetErrorString(nr));
+        }
+    }
+    RT_GNCCL(g, r.GroupEnd());
+    for (int i = 0; i < n; ++i) {
+        int rc = rt_strip_unpack(g->ctx[(size_t)i], strip_rows, n, i, g->gathered[(size_t)i]);
+        if (rc != RT_OK) return gfail(g, rc, rt_last_error(g->ctx[(size_t)i]));
+    }
+    return RT_OK;
+}
+
+int rt_group_render_frames(RtGroup* g, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, int mode,
+                           int32_t strip_rows, int32_t frames) {
     if (!g || !camera || !pc) return RT_ERR_INVALID_ARGUMENT;
-    if (frames_per_device < 1 || frames_per_device > 4096) return gfail(g, RT_ERR_INVALID_ARGUMENT, "frames_per_device out of range");
+    if (mode != RT_GROUP_STRIPS && mode != RT_GROUP_SAMPLES) return gfail(g, RT_ERR_INVALID_ARGUMENT, "unknown group mode");
+    if (frames < 1 || frames > 4096) return gfail(g, RT_ERR_INVALID_ARGUMENT, "frames out of range");
     const int n = (int)g->ctx.size();
     RtParams p;
     if (params) p = *params; else rt_default_params(&p);
+    std::vector<RtPushConstants> pcs((size_t)frames);
+    if (mode == RT_GROUP_STRIPS) {
+        // frames frameCount, frameCount + 1, ...: every device its rows of each, one exchange at the end
+        for (int k = 0; k < frames; ++k) {
+            pcs[(size_t)k] = *pc;
+            pcs[(size_t)k].frameCount = pc->frameCount + (uint32_t)k;
+            if (k > 0) pcs[(size_t)k].reset_frame_accumulation = 0;
+        }
+        return render_strips(g, camera, pcs.data(), frames, p, strip_rows);
+    }
     p.strip_rows = 0; p.strip_count = 1; p.strip_index = 0;
-    // device i renders the frames numbered frameCount + i, + i + n, ...: what frames_per_device calls of
+    // device i renders the frames numbered frameCount + i, + i + n, ...: what `frames` calls of
     // rt_group_render_frame(RT_GROUP_SAMPLES) with frameCount advanced by n each time give, but every device gets
     // its frames in one rt_render_frames call (one launch where that applies); pc's reset applies to a device's first
-    std::vector<RtPushConstants> pcs((size_t)frames_per_device);
     for (int i = 0; i < n; ++i) {
-        for (int k = 0; k < frames_per_device; ++k) {
+        for (int k = 0; k < frames; ++k) {
             pcs[(size_t)k] = *pc;
             pcs[(size_t)k].frameCount = pc->frameCount + (uint32_t)(i + k * n);
             if (k > 0) pcs[(size_t)k].reset_frame_accumulation = 0;
         }
-        int rc = rt_render_frames(g->ctx[(size_t)i], camera, pcs.data(), frames_per_device, &p);
+        int rc = rt_render_frames(g->ctx[(size_t)i], camera, pcs.data(), frames, &p);
         if (rc != RT_OK) return gfail(g, rc, rt_last_error(g->ctx[(size_t)i]));
     }
     return RT_OK;
@@ -331,47 +388,7 @@ int rt_group_render_frame(RtGroup* g, const RtCamera* camera, const RtPushConsta
         }
         return RT_OK;
     }
-    if (strip_rows <= 0) return gfail(g, RT_ERR_INVALID_ARGUMENT, "strip_rows must be positive");
-    // one frame shared by row strips: every device renders its rows with global pixel coordinates (the
-    // bits of a one-GPU frame), packs them, and one all-gather completes the frame everywhere
-    const int32_t w = g->ctx[0]->width, h = g->ctx[0]->height;
-    if (w <= 0 || h <= 0) return gfail(g, RT_ERR_NO_FRAMEBUFFER, "rt_group_resize has not been called");
-    const int32_t key[4] = {w, h, strip_rows, n};
-    if (memcmp(key, g->stage_key, sizeof key) != 0) {
-        free_group_buffers(g);
-        g->staging_bytes = rt_strip_staging_bytes(w, h, strip_rows, n);
-        for (int i = 0; i < n; ++i) {
-            RT_GHIP(g, hipSetDevice(g->ctx[(size_t)i]->device));
-            RT_GHIP(g, hipStreamSynchronize(g->ctx[(size_t)i]->stream));
-            RT_GHIP(g, hipMalloc(&g->staging[(size_t)i], g->staging_bytes));
-            RT_GHIP(g, hipMalloc(&g->gathered[(size_t)i], g->staging_bytes * (size_t)n));
-            RT_GHIP(g, hipMemsetAsync(g->staging[(size_t)i], 0, g->staging_bytes, g->ctx[(size_t)i]->stream));
-        }
-        memcpy(g->stage_key, key, sizeof key);
-    }
-    for (int i = 0; i < n; ++i) {
-        RtContext* c = g->ctx[(size_t)i];
-        p.strip_rows = strip_rows; p.strip_count = n; p.strip_index = i;
-        int rc = rt_render_frame(c, camera, pc, &p);
-        if (rc == RT_OK) rc = rt_strip_pack(c, strip_rows, n, i, g->staging[(size_t)i]);
-        if (rc != RT_OK) return gfail(g, rc, rt_last_error(c));
-    }
-    Rccl& r = rccl();
-    RT_GNCCL(g, r.GroupStart());
-    for (int i = 0; i < n; ++i) {
-        ncclResult_t nr = r.AllGather(g->staging[(size_t)i], g->gathered[(size_t)i], g->staging_bytes, ncclChar, g->comm[(size_t)i],
-                                      g->ctx[(size_t)i]->stream);
-        if (nr != ncclSuccess) {
-            (void)r.GroupEnd();
-            return gfail(g, RT_ERR_HIP, std::string("ncclAllGather: ") + r.GetErrorString(nr));
-        }
-    }
-    RT_GNCCL(g, r.GroupEnd());
-    for (int i = 0; i < n; ++i) {
-        int rc = rt_strip_unpack(g->ctx[(size_t)i], strip_rows, n, i, g->gathered[(size_t)i]);
-        if (rc != RT_OK) return gfail(g, rc, rt_last_error(g->ctx[(size_t)i]));
-    }
-    return RT_OK;
+    return render_strips(g, camera, pc, 1, p, strip_rows);
 }
 
 int rt_group_reduce_samples(RtGroup* g) {

@@ -389,9 +389,9 @@ class Group:
         self._chk(self._lib.rt_group_render_frame(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None,
                                                   int(mode), int(strip_rows)), "rt_group_render_frame")
 
-    def render_frames(self, camera, pc, params, frames_per_device: int):
+    def render_frames(self, camera, pc, params, mode: int, strip_rows: int, frames: int):
         self._chk(self._lib.rt_group_render_frames(self._h, C.byref(camera), C.byref(pc), C.byref(params) if params else None,
-                                                   int(frames_per_device)), "rt_group_render_frames")
+                                                   int(mode), int(strip_rows), int(frames)), "rt_group_render_frames")
 
     def reduce_samples(self):
         self._chk(self._lib.rt_group_reduce_samples(self._h), "rt_group_reduce_samples")

@@ -89,25 +89,33 @@ def test_group_of_one_device_equals_render_frame():
         g.close()
 
 
-def test_group_sample_batch_equals_frame_by_frame():
-    """rt_group_render_frames: a device's frames of a sample batch in one call (fused into one launch at this size)
-    against the same frames one rt_group_render_frame call each."""
+@pytest.mark.parametrize("mode", [capi.RT_GROUP_SAMPLES, capi.RT_GROUP_STRIPS])
+def test_group_batch_of_frames_equals_frame_by_frame(mode):
+    """rt_group_render_frames: the frames of a batch in one call per device (fused into one launch at this size, one
+    exchange for the batch) against the same frames one rt_group_render_frame call each."""
     scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
     W, H, F = 512, 288, 5
     cam, params = default_camera(W, H), make_params(2, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED)
     g = Group([0])
     try:
         g.upload_scene(scene)
+
+        def result():
+            if mode == capi.RT_GROUP_SAMPLES:
+                g.reduce_samples()
+                return g.read_total()
+            g.sync()
+            return g.context(0).read_accum()
+
         g.resize(W, H)
         for f in range(F):
-            g.render_frame(cam, scene.push_constants(0.0, 10 + f * len(g), f == 0), params, capi.RT_GROUP_SAMPLES, 0)
-        g.reduce_samples()
-        want_acc, want_cnt = g.read_total()
+            g.render_frame(cam, scene.push_constants(0.0, 10 + f * len(g), f == 0), params, mode, 9)
+        want_acc, want_cnt = result()
+        want_acc, want_cnt = want_acc.copy(), want_cnt.copy()
         g.resize(W, H)
-        g.render_frames(cam, scene.push_constants(0.0, 10, True), params, F)
+        g.render_frames(cam, scene.push_constants(0.0, 10, True), params, mode, 9, F)
         assert g.context(0).stats().frames == F
-        g.reduce_samples()
-        acc, cnt = g.read_total()
+        acc, cnt = result()
         assert bit_equal_pixels(acc, want_acc).all() and np.array_equal(cnt, want_cnt) and (cnt == F).all()
     finally:
         g.close()
