@@ -437,14 +437,15 @@ static bool pooled_fits(const RtContext* c, const RtParams& p) {
     return p.spp <= 65535 && p.max_bounces <= 65534 && c->n_lights <= 32768 && c->n_materials <= 65536;
 }
 
-// Paths in flight per pooled workgroup: all the slots while the scene stays in the L2 caches; a scene far
-// beyond them (the 84 MB of the 1.07 M-triangle scene against 8 x 4 MB) runs faster with fewer rays
-// competing for the caches (measured on that scene, binary tree: 1408 slots 15.8 ms, 1152 15.1, 896 14.7, 768 14.9;
-// four-wide tree: 1392 slots 14.0 ms, 1152 13.5, 896 13.2, 768 13.3).
-static int pool_slots(const RtContext* c) {
+// Paths in flight per pooled workgroup.  A single frame of a scene far beyond the L2 caches (the 84 MB of the
+// 1.07 M-triangle scene against 8 x 4 MB) runs faster with fewer (final kernel: 1392 slots 12.35 ms, 1152 11.9, 896 11.75):
+// its long rays make the last generation of paths expensive, and fewer slots make that generation smaller.  A launch
+// of several frames has one such generation for all of them and wants every slot (4 frames: 896 slots 10.84 ms per
+// frame, 1152 10.25, 1392 10.10), as do the scenes that fit the caches.
+static int pool_slots(const RtContext* c, int n_frames) {
     if (c->opt.pool_slots > 0) return c->opt.pool_slots;
     const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
-    return scene_bytes > ((size_t)16 << 20) ? 896 : 0;
+    return (scene_bytes > ((size_t)16 << 20) && n_frames == 1) ? 896 : 0;
 }
 
 // Children per node of the tree the pooled kernel walks.  The four-wide tree takes about half the node visits
@@ -490,7 +491,7 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
                 sc.nodes = (const float4*)c->d_nodes_wide;
             }
             c->last_width = p.accel == RT_ACCEL_BVH ? width : 0;
-            RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c),
+            RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c, fa.n_frames),
                                        c->stream));
         } else {
             // the single kernel keeps a stack of rtd::kStackDepth entries per lane in LDS: the wide tree where that holds it
