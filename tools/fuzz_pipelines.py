@@ -40,7 +40,7 @@ for k in range(cases):
     scenes["random"] = random_scene(rng)
     name = rng.choice(list(scenes))
     s = scenes[name]
-    W, H = rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 130, 200, 333, 640]), rng.choice([1, 3, 8, 17, 40, 72, 129, 360])
+    W, H = rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 130, 200, 333, 640, 801]), rng.choice([1, 3, 8, 17, 40, 72, 129, 360, 451])
     spp, mb, frames = rng.choice([1, 1, 2, 3, 5]), rng.choice([0, 1, 2, 4, 9, 20]), rng.choice([1, 2, 3])
     sky = rng.choice([0, 0, 1, 2, 3, 4])
     sc = rng.choice([1, 1, 2, 3])
@@ -59,6 +59,17 @@ for k in range(cases):
         if not same or (g["stats"].bvh_width != 4 and g["total_rays"] != 0):
             ok = False
             print(f"  MISMATCH {label} (width {g['stats'].bvh_width})")
+    if frames > 1:
+        # the same frames in one rt_render_frames call (one launch where the image is large enough), without the debug outputs
+        from raytracer_amd.renderer import default_camera, make_params
+        cam = default_camera(W, H)
+        p = make_params(spp, mb, capi.RT_ACCEL_BVH, strip[0], strip[1], strip[2], capi.RT_FLAG_POOLED, sky)
+        ctx.upload_scene(s); ctx.resize(W, H)
+        ctx.render_frames(cam, [s.push_constants(0.0, f, f == 0) for f in range(frames)], p)
+        acc, cnt = ctx.read_accum()
+        if not (bit_equal_pixels(acc, ref["accum"]).all() and np.array_equal(cnt, ref["counts"]) and np.array_equal(ctx.read_bgra8(), ref["bgra"])):
+            ok = False
+            print(f"  MISMATCH rt_render_frames ({ctx.stats().frames} frames in the launch)")
     if W * H <= 8000 and name != "teapot":
         o = oracle_frames(s, W, H, spp, mb, frames=frames, strip=strip, skybox=sky)
         f = gpu_frames(ctx, s, W, H, accel=capi.RT_ACCEL_FLAT, **kw)
