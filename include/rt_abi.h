@@ -240,7 +240,7 @@ int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstant
 /* n_frames consecutive rt_render_frame calls with one camera and pcs[0 .. n_frames - 1], with the same result bit for
  * bit - the reference's frame loop with a still camera (main.cpp:2160-2171: frameCount differs from frame to frame,
  * the accumulation is reset at most by the first).  Where the frames differ in frameCount only and the pooled kernel
- * applies (BVH search, no debug outputs, an image of at least 2 048 tiles), up to 16 frames at a time share ONE launch:
+ * applies (BVH search, no debug outputs, an image of 64 tiles to 4 M pixels), up to 16 frames at a time share ONE launch:
  * a pixel's frames follow each other on one XCD, so the drain of one frame's last paths is hidden behind the next
  * frame's first.  Otherwise the frames are rendered one by one.  RtStats then describe the last launch (rays: all its
  * frames). */

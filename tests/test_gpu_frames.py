@@ -82,7 +82,7 @@ def test_fused_frames_under_heavy_overlap(ctx, W, H, spp, mb, n, rounds):
 def test_frames_that_cannot_be_fused_are_rendered_one_by_one(ctx):
     scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
     params = make_params(2, 3, capi.RT_ACCEL_BVH, 0, 1, 0, 0)
-    for (W, H, vary_time, flags) in ((96, 54, False, 0), (512, 288, True, capi.RT_FLAG_POOLED), (512, 288, False, capi.RT_FLAG_SINGLE_KERNEL)):
+    for (W, H, vary_time, flags) in ((40, 30, False, 0), (512, 288, True, capi.RT_FLAG_POOLED), (512, 288, False, capi.RT_FLAG_SINGLE_KERNEL)):
         cam = default_camera(W, H)
         params.flags = flags
         pcs = [scene.push_constants(1.0 * k if vary_time else 0.0, k, k == 0) for k in range(3)]
