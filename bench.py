@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = --frames-per-launch frames (8 unless told otherwise; a frame = one execution of the reference
+One step = --frames-per-launch frames (16 unless told otherwise; a frame = one execution of the reference
 shader's main() per pixel) of the workload BASELINE.json's metric is quoted on: Cornell box + teapot.glb,
 1920x1080, 16 samples per pixel, 4 bounces, still camera, frameCount advancing from frame to frame as in the
 reference's frame loop.  The frames of a step are handed to the library in one rt_render_frames call, which
@@ -82,7 +82,7 @@ def main() -> None:
     ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled"],
                     help="schedule of the per-path program (same results): the library's own choice, the single "
                          "persistent kernel, or the pooled kernel (LDS queues)")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
+    ap.add_argument("--frames-per-launch", type=int, default=16,
                     help="row-strip / single-GPU runs: frames of the still camera handed to the library per step (rt_render_frames "
                          "fuses up to 16 into one launch; with several ranks the strips are exchanged once per step); "
                          "1 = one rt_render_frame call (and one exchange) per frame")
@@ -90,6 +90,11 @@ def main() -> None:
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
     args = ap.parse_args()
+    # stdout carries ONE line, the result; whatever the libraries print there meanwhile (RCCL announces its version
+    # on stdout) goes to stderr: file descriptor 1 is pointed at 2 until the line is written
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,7 +337,8 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
 
     ctx.close()
     if collective:

@@ -14,7 +14,7 @@ cp $out/prof_c3/*/*kernel_stats.csv $out/c3_kernel_stats.csv
 # counters per FRAME: one frame per launch (the bench's default hands the library 8 frames per launch; that kernel follows)
 BENCH_ARGS="--pipeline pooled --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c3_pooled || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<2, false, false>" 1 > $out/c3_pooled_pmc.txt
-BENCH_ARGS="--pipeline pooled" bash tools/pmc_passes.sh $out/pmc_c3_fused || exit 1
+BENCH_ARGS="--pipeline pooled --frames-per-launch 8" bash tools/pmc_passes.sh $out/pmc_c3_fused || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_fused "pool_kernel<2, false, true>" 1 > $out/c3_pooled_fused8_pmc.txt
 BENCH_ARGS="--pipeline single --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c3_single || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_single "render_kernel<2, false>" 1 > $out/c3_single_pmc.txt
