@@ -51,6 +51,7 @@ constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
 constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
+enum { kLive = 7 };  // PoolLds::hc[kLive]: the live count and the abort bit
 enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, Q_LIT = 4, Q_PIXEL = 5, Q_MISS = 6, kQueues = 7 };
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
@@ -67,15 +68,11 @@ struct PoolLds {
     uint32_t flags[(kPool + 3) / 4];  // one byte per slot: LF_* of the sample's light query (changed by LDS atomics on the word)
     // queues
     uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
-    // What every wave polls once per round, in one 48-byte block (three 16-byte LDS reads):
+    // What every wave polls once per round, in one 32-byte block (two 16-byte LDS reads):
     // hc[q] = next ring position to pop << 16 | entries published and not yet claimed (one word, so
-    // that a pop claims entries and advances the position with a single compare-and-swap);
-    // live = slots that still carry a pixel; abort = a bound on waiting was exceeded (never in a
-    // correct run).
-    alignas(16) uint32_t hc[8];      // kQueues used
-    uint32_t live;
-    uint32_t abort;
-    uint32_t ctl_pad[2];
+    // that a pop claims entries and advances the position with a single compare-and-swap), for the kQueues queues;
+    // hc[7] = slots that still carry a pixel | bit 31: a bound on waiting was exceeded (never in a correct run).
+    alignas(16) uint32_t hc[8];
     uint32_t tail[kQueues];          // next ring position to push
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
@@ -151,12 +148,11 @@ RT_DEV void lds_poke(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
 RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     const u32x4 a = *(const volatile lds_u32x4*)&L.hc[0];
     const u32x4 b = *(const volatile lds_u32x4*)&L.hc[4];
-    const u32x4 d = *(const volatile lds_u32x4*)&L.live;
     PoolCtl c;
     c.count[0] = a.x & 0xffffu; c.count[1] = a.y & 0xffffu; c.count[2] = a.z & 0xffffu; c.count[3] = a.w & 0xffffu;
     c.count[4] = b.x & 0xffffu; c.count[5] = b.y & 0xffffu; c.count[6] = b.z & 0xffffu;
-    c.live = d.x;
-    c.abort = d.y;
+    c.live = b.w & 0x7fffffffu;
+    c.abort = b.w >> 31;
     return c;
 }
 
@@ -237,7 +233,7 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
         volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(pos + rank) & (kRing - 1)];
         uint32_t v = *e, tries = 0;
         while (v == kEmpty && ++tries < kSpinLimit) v = *e;  // the pusher is between its reservation and its store
-        if (v == kEmpty) atomicExch(&L.abort, 1u);
+        if (v == kEmpty) atomicOr(&L.hc[kLive], 0x80000000u);
         *e = kEmpty;
         item = v;
         got = (v != kEmpty);
@@ -314,7 +310,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
         }
     }
     const unsigned long long d = __ballot(dead);
-    if (d != 0ull && lane_id() == __ffsll((long long)d) - 1) atomicSub(&L.live, (uint32_t)__popcll(d));
+    if (d != 0ull && lane_id() == __ffsll((long long)d) - 1) atomicSub(&L.hc[kLive], (uint32_t)__popcll(d));
     return started;  // the caller queues these slots for the search
 }
 
@@ -339,7 +335,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     // overflows the caches runs faster with fewer rays competing for them.
     const uint32_t share = (fa.total_slots * (uint32_t)(BATCH ? fa.n_frames : 1) + gridDim.x - 1u) / gridDim.x;
     const uint32_t per_wave = share >= (uint32_t)slots_cap ? (uint32_t)slots_cap / (uint32_t)kWaves : (share + kWaves - 1u) / kWaves;
-    if (tid == 0) { L.live = per_wave * kWaves; L.abort = 0; L.ctl_pad[0] = 0; L.ctl_pad[1] = 0; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
+    if (tid == 0) { L.hc[kLive] = per_wave * kWaves; L.res_lock = 0; L.res_next = 0; L.res_end = 0; }
     __syncthreads();
     for (uint32_t g = 0; g * 64u < per_wave; ++g) {
         const uint32_t mine = (uint32_t)wave * (uint32_t)(kPool / kWaves) + g * 64u + (uint32_t)lane;
@@ -520,8 +516,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             }
         }
         if (__ballot(slot >= 0) == 0ull) {
-            if (lds_peek(&L.live) == 0u) break;
-            if (++guard > kGuardLimit) { atomicExch(&L.abort, 1u); break; }
+            if ((lds_peek(&L.hc[kLive]) & 0x7fffffffu) == 0u) break;
+            if (++guard > kGuardLimit) { atomicOr(&L.hc[kLive], 0x80000000u); break; }
             __builtin_amdgcn_s_sleep(8);
             continue;
         }
@@ -583,7 +579,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }
-        if (lds_peek(&L.abort) != 0u) *(volatile uint32_t*)kernarg_frame().abort_flag = 1u;
+        if ((lds_peek(&L.hc[kLive]) >> 31) != 0u) *(volatile uint32_t*)kernarg_frame().abort_flag = 1u;
     }
 }
 
