@@ -187,6 +187,10 @@ typedef struct RtStats {
                                RT_OPT_BVH_WIDTH; nodes_visited then counts four-wide nodes); 0 for the flat loops   */
     int32_t  frames;        /* frames the last launch rendered (rt_render_frames fuses up to 16; else 1); rays, the
                                traversal counts and kernel_ms are that launch's                                    */
+    int32_t  search_queue_peak; /* pooled pipeline with TRAVERSAL_STATS: the most rays any workgroup's waves saw waiting
+                                   for a lane at once ...                                                            */
+    int32_t  search_queue_size; /* ... and what that queue holds (a ray pushed beyond it would be lost, and the frame
+                                   would fail with RT_ERR_HIP instead of finishing)                                  */
 } RtStats;
 
 typedef struct RtContext RtContext;

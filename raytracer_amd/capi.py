@@ -108,7 +108,8 @@ class RtStats(C.Structure):
                 ("kernel_ms", C.c_float), ("bvh_nodes", C.c_int32), ("bvh_depth", C.c_int32),
                 ("total_prims", C.c_int32), ("pipeline", C.c_int32),
                 ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64),
-                ("bvh_width", C.c_int32), ("frames", C.c_int32)]
+                ("bvh_width", C.c_int32), ("frames", C.c_int32),
+                ("search_queue_peak", C.c_int32), ("search_queue_size", C.c_int32)]
 
 
 class RtSceneView(C.Structure):

@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     };
     uint32_t n_rays = 0, n_nodes = 0, n_tests = 0, n_leaf_steps = 0, guard = 0;
     unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
+    uint32_t search_peak = 0;  // STATS: the most rays this wave saw waiting in the search queue
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
     unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0, step_cycles = 0;  // STATS: wave cycles (step_cycles: the part of search_cycles inside the burst of steps)
@@ -372,6 +373,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     for (;;) {
         const PoolCtl ctl = poll_ctl(L);
         if (ctl.abort != 0u) break;
+        if (STATS) search_peak = ctl.count[Q_SEARCH] > search_peak ? ctl.count[Q_SEARCH] : search_peak;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
         int q = Q_NEXT;
@@ -576,6 +578,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 10), __builtin_readcyclecounter() - t_begin - shade_cycles - search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 12), search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 42), step_cycles);
+            atomicMax(fa.counters + 44, search_peak);
+            fa.counters[45] = (uint32_t)kRing;
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }

@@ -11,9 +11,9 @@ Moeller-Trumbore result lies outside the padded leaf box); their share must stay
 import numpy as np
 import pytest
 
-from helpers import bit_equal_pixels, gpu_frames, oracle_frames
+from helpers import DEBUG_FLAGS, bit_equal_pixels, gpu_frames, oracle_frames
 from raytracer_amd import capi
-from raytracer_amd.renderer import Context, Controller, Scene, look_camera, make_params
+from raytracer_amd.renderer import Context, Controller, Scene, default_camera, look_camera, make_params
 
 pytestmark = pytest.mark.gpu
 
@@ -490,3 +490,40 @@ def test_bounded_light_queries_leave_the_image_unchanged(ctx, teapot, kind, pipe
     assert bit_equal_pixels(exact["accum"], fast["accum"]).all()
     assert np.array_equal(exact["counts"], fast["counts"]) and np.array_equal(exact["bgra"], fast["bgra"])
     assert np.array_equal(exact["primary_ids"], fast["primary_ids"]) and exact["total_rays"] == fast["total_rays"]
+
+
+@pytest.mark.parametrize("kind", ["wall", "wall_lamp", "wall_lamp_floor"])
+def test_pooled_queues_when_every_ray_ends_at_once(ctx, kind):
+    """A 1080p frame of one or two triangles that fill the view: every search ends within its first burst of
+    steps, so a workgroup's 1 392 paths arrive at the first-hit stage together and each sends a light query and
+    a bounce ray back at once - the fullest the pooled kernel's search queue can get (its ring holds 2 048 rays).
+    The frame must complete (no abandoned-frame error from rt_sync / rt_read_*) and equal the single kernel's
+    bit for bit, without the hash (bounded light queries, fused frames) as well as with it."""
+    s = Scene(capi.RT_SCENE_EMPTY)
+    white = s.add_material((0.8, 0.8, 0.8, 1), (0, 0, 0, 0), (1, 1, 1, 0.5), (0, 0, 0, 0), 0.7, 0.0, 1.5, 0.0)
+    lamp = s.add_material((1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 1, 0.5), (1.0, 0.9, 0.7, 12.0), 0.5, 0.0, 1.5, 0.0)
+    s.add_triangle((-40.0, -30.0, 4.0), (45.0, -30.0, 4.0), (2.75, 60.0, 4.0), white)
+    if kind != "wall":
+        s.add_triangle((0.0, 5.0, 0.0), (1.0, 5.0, 0.0), (0.0, 5.0, 1.0), lamp)
+    if kind == "wall_lamp_floor":
+        s.add_triangle((-60.0, 0.0, -20.0), (2.75, 0.0, 90.0), (70.0, 0.0, -20.0), white)
+    W, H = 1920, 1080
+    for flags in (DEBUG_FLAGS, 0):
+        a = gpu_frames(ctx, s, W, H, spp=4, max_bounces=4, frames=2, flags=flags | capi.RT_FLAG_SINGLE_KERNEL)
+        b = gpu_frames(ctx, s, W, H, spp=4, max_bounces=4, frames=2, flags=flags | capi.RT_FLAG_POOLED)
+        assert b["stats"].pipeline == capi.RT_PIPELINE_POOLED
+        if flags:
+            assert_identical(b, a)
+        else:
+            assert bit_equal_pixels(a["accum"], b["accum"]).all() and np.array_equal(a["bgra"], b["bgra"])
+            assert a["total_rays"] == b["total_rays"]
+    # the same frames in one fused launch
+    cam = default_camera(W, H)
+    ctx.render_frames(cam, [s.push_constants(0.0, f, f == 0) for f in range(2)], make_params(4, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED))
+    acc, cnt = ctx.read_accum()
+    assert ctx.stats().frames == 2
+    assert bit_equal_pixels(acc, a["accum"]).all() and (cnt == 2).all()
+    # what the instrumented kernel saw waiting in a workgroup's search queue stays inside its ring
+    ctx.render_frame(cam, s.push_constants(0.0, 2, False), make_params(4, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED | capi.RT_FLAG_TRAVERSAL_STATS))
+    st = ctx.stats()
+    assert 0 < st.search_queue_peak <= st.search_queue_size * 7 // 8, (st.search_queue_peak, st.search_queue_size)

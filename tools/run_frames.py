@@ -32,4 +32,5 @@ for f in range(n):
         print(f"  search steps: lanes with a ray {st.busy_lane_iterations / (64 * max(1, st.wave_iterations)):.3f}, of those taking the step "
               f"{st.lane_iterations / max(1, st.busy_lane_iterations):.3f}; bursts of steps {st.cycles_steps / tot:.3f} of all wave cycles "
               f"({st.cycles_steps / max(1, st.wave_iterations):.0f} cycles per wave step), exchange of rays {(st.cycles_search - st.cycles_steps) / tot:.3f}")
+        print(f"  search queue: at most {st.search_queue_peak} rays waiting of {st.search_queue_size} it holds")
         print("  job fill: " + ", ".join(f"{n} {(v >> 32) / max(1, v & 0xffffffff):.1f}/64 x {v & 0xffffffff}" for n, v in zip(names, list(st.cycles_shade_parts)[:4])), flush=True)
