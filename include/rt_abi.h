@@ -307,7 +307,7 @@ void* rt_get_stream(RtContext* ctx);
 /* Replaces vkWaitForFences / vkQueueWaitIdle (main.cpp:1310-1312). */
 int rt_sync(RtContext* ctx);
 
-const char* rt_last_error(RtContext* ctx); /* ctx may be NULL: error of the last failed rt_create */
+const char* rt_last_error(RtContext* ctx); /* ctx may be NULL: error of the calling thread's last failed rt_create */
 void rt_default_params(RtParams* out);     /* spp 5, max_bounces 20, BVH, all rows, no flags     */
 int  rt_abi_version(void);
 

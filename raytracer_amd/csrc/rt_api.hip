@@ -18,7 +18,7 @@
 #include "rt_context.h"
 
 namespace {
-std::string g_create_error;
+thread_local std::string g_create_error;  // what rt_last_error(NULL) returns: the calling thread's last failed rt_create
 }
 
 namespace rtapi {
@@ -272,8 +272,10 @@ int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, co
     RT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     int rc;
-    if ((rc = upload_array(c, &c->d_prims_bvh, bvh.prims.data(), bvh.prims.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return rc;
-    if ((rc = upload_array(c, &c->d_prims_flat, flat.data(), flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return rc;
+    // (a failed upload still waits for the copies already queued: they read the host vectors below)
+    auto bail = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+    if ((rc = upload_array(c, &c->d_prims_bvh, bvh.prims.data(), bvh.prims.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_prims_flat, flat.data(), flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
     // device form of a node: each child as the traversal's cursor word (an internal node's index, or
     // bit 31 | (count - 1) << 28 | first record for a leaf), the count of an unused slot -1
     std::vector<rt::BvhNode> dev_nodes(bvh.nodes);
@@ -281,13 +283,13 @@ int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, co
         if (n.child0 < 0) n.count0 = -1; else if (n.count0 > 0) n.child0 = (int32_t)(0x80000000u | ((uint32_t)(n.count0 - 1) << 28) | (uint32_t)n.child0);
         if (n.child1 < 0) n.count1 = -1; else if (n.count1 > 0) n.child1 = (int32_t)(0x80000000u | ((uint32_t)(n.count1 - 1) << 28) | (uint32_t)n.child1);
     }
-    if ((rc = upload_array(c, &c->d_nodes, dev_nodes.data(), dev_nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_nodes, dev_nodes.data(), dev_nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return bail(rc);
     rt::HostWideBvh wide;
     rt::collapse_wide(bvh, wide);
-    if ((rc = upload_array(c, &c->d_nodes_wide, wide.nodes.data(), wide.nodes.size() * sizeof(rt::WideNode), 128)) != RT_OK) return rc;
-    if ((rc = upload_array(c, &c->d_materials, materials, (size_t)n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return rc;
-    if ((rc = upload_array(c, &c->d_lights, lights, (size_t)n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return rc;
-    if ((rc = upload_array(c, &c->d_triangles, triangles, (size_t)n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return rc;
+    if ((rc = upload_array(c, &c->d_nodes_wide, wide.nodes.data(), wide.nodes.size() * sizeof(rt::WideNode), 128)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_materials, materials, (size_t)n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_lights, lights, (size_t)n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_triangles, triangles, (size_t)n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return bail(rc);
     RT_HIP(c, hipStreamSynchronize(c->stream));  // host vectors above go out of scope
     c->n_prims = (int32_t)flat.size();
     c->n_spheres = n_spheres;

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -95,16 +96,22 @@ struct Rccl {
     std::string error;
 };
 
+void load_rccl(Rccl& r);
 Rccl& rccl() {
     static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
+    static std::once_flag once;  // groups may be created from several threads
+    std::call_once(once, [] { load_rccl(r); });
+    return r;
+}
+void load_rccl(Rccl& r) {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
     }
     if (!r.handle) {
-        r.error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "");
-        return r;
+        const char* why = dlerror();  // (a second call would return null: the message is consumed by the first)
+        r.error = std::string("cannot load librccl.so: ") + (why ? why : "");
+        return;
     }
     auto sym = [&](const char* n) {
         void* p = dlsym(r.handle, n);
@@ -118,7 +125,6 @@ Rccl& rccl() {
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-    return r;
 }
 
 }  // namespace
