@@ -35,11 +35,13 @@ from raytracer_amd.workloads import WORKLOADS, workload_camera  # noqa: E402
 FRAMES_PER_BATCH = 16  # sample sharding: frames per progressive batch (c4: 16 x 4 spp = 64 spp)
 STRIP_ROWS = 9  # 1080 / 9 = 120 strips: divisible by 1, 2, 4 and 8 ranks
 
-# MI355X vector FP32 peaks (spec): 256 CU x 4 SIMD x 2.4 GHz x 16 lanes x 2 flop (FMA) = 78.6 TFLOP/s for the
-# one-result-per-lane instructions this build uses (-fno-slp-vectorize: packed v_pk_*_f32 issue no faster here
-# and cost register shuffles); 157.3 TFLOP/s with packed FMA (two results per lane).
-PEAK_VALU_TFLOPS_PACKED = 157.3
-PEAK_VALU_TFLOPS = 78.6
+# MI355X vector FP32 peak (spec): 256 CU x 4 SIMD x 32 lanes per clock x 2 flop (FMA) x 2.4 GHz = 157.3 TFLOP/s.  A SIMD
+# issues a wave's v_add / v_mul / v_fma_f32 over 2 clocks - plain instructions, no packing needed: tools/ubench/valu_rate
+# measures 2.2-2.4 clocks per wave instruction at 4-8 waves per SIMD, 144 TFLOP/s (profiles/r02_valu_rate.txt) - and
+# everything else the search is made of (min / max 4.7 clocks, integer and address arithmetic 4.3, a compare + select
+# pair 8.3, reciprocal 8.5) over 4 clocks or more.  78.6 TFLOP/s is what the peak would be at 4 clocks per instruction.
+PEAK_VALU_TFLOPS = 157.3
+PEAK_VALU_TFLOPS_4CLK = 78.6
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -316,11 +318,13 @@ def main() -> None:
                 "kernel": {"single": "render_kernel", "pooled": "pool_kernel"}[pipeline],
                 "achieved": achieved_tflops,
                 "peak": PEAK_VALU_TFLOPS,
-                "peak_note": "vector FP32 with one result per lane (what this build issues); with packed FMA the peak is "
-                             f"{PEAK_VALU_TFLOPS_PACKED} TFLOP/s (frac_packed)",
+                "peak_note": "vector FP32 peak of the guide and the spec sheet (plain v_fma_f32 at 2 clocks per wave instruction: measured "
+                             "144 TFLOP/s, profiles/r02_valu_rate.txt); frac_4clk prices the same number against "
+                             f"{PEAK_VALU_TFLOPS_4CLK} TFLOP/s, the rate at 4 clocks per instruction, which is what compares, selects, "
+                             "min / max and integer arithmetic cost",
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_VALU_TFLOPS,
-                "frac_packed": achieved_tflops / PEAK_VALU_TFLOPS_PACKED,
+                "frac_4clk": achieved_tflops / PEAK_VALU_TFLOPS_4CLK,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "avg_kernel_ms": avg_kernel_ms,
