@@ -156,10 +156,25 @@ RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     return c;
 }
 
+// The search queue may be asked for more places than its ring has: a slot can have two rays waiting (its path's
+// and its light query's), 2 * kPool > kRing, although the lanes hold most rays and the fullest it has been seen is
+// three quarters.  A pusher therefore never overwrites: a place that still holds an entry of the lap before is waited
+// for - its popper empties it - within the usual bound.  (The other queues hold one entry per slot at most.)  The wait's
+// LDS read is only paid when the wave's last look at the queues found the ring at least half full (`crowded`), which
+// covers a queue that fills up over several rounds; what it does not cover is a thousand rays pushed by the other
+// waves within one job of this wave onto a ring it saw half empty (from an empty ring, the start of a frame, all
+// sixteen waves' first-hit jobs together fill it exactly).  A ray that does get overwritten is not lost silently: its
+// pixel never ends, the bound on waiting trips and the frame is reported as abandoned.
+RT_DEV void wait_for_place(PoolLds& L, volatile lds_u16* e) {
+    uint32_t tries = 0;
+    while (*e != kEmpty && ++tries < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+    if (tries >= kSpinLimit) atomicOr(&L.hc[kLive], 0x80000000u);
+}
+
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
 // LDS and device memory) is visible to the workgroup before an entry can be read: state stores,
 // release fence, entry store, count.
-RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
+RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item, bool crowded = false) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
     const int leader = __ffsll((long long)m) - 1;
@@ -170,7 +185,11 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     // Release BEFORE the entry store: entries are claimed by ring position, so another wave's count
     // may expose this position, and its popper takes the entry the moment it stops being kEmpty.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (want) *(volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    if (want) {
+        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)];
+        if (q == Q_SEARCH && crowded) wait_for_place(L, e);
+        *e = (uint16_t)item;
+    }
     if (lane_id() == leader) atomicAdd(&L.hc[q], n);  // LDS operations of one wave complete in order: after the entries
 }
 
@@ -178,7 +197,7 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
 // nothing) and its item; lane k reserves for queue k, so the wave pays one LDS atomic round trip
 // however many queues receive entries.  MASK: the queues this call site can name (the others cost nothing).
 template <unsigned MASK>
-RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
+RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item, bool crowded = false) {
     unsigned long long m[kQueues];
     unsigned long long any = 0ull;
 #pragma unroll
@@ -203,7 +222,11 @@ RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
         if (q == k) { base = pk; mk = m[k]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // before the entry store, as in queue_push
-    if (q >= 0) *(volatile lds_u16*)&L.items[q][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)] = (uint16_t)item;
+    if (q >= 0) {
+        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)];
+        if (((MASK >> Q_SEARCH) & 1u) && crowded && q == Q_SEARCH) wait_for_place(L, e);
+        *e = (uint16_t)item;
+    }
     if (lane < kQueues && n_mine != 0u) atomicAdd(&L.hc[lane], n_mine);
 }
 
@@ -373,6 +396,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     for (;;) {
         const PoolCtl ctl = poll_ctl(L);
         if (ctl.abort != 0u) break;
+        const bool crowded = ctl.count[Q_SEARCH] >= (uint32_t)(kRing / 2);  // pushes to the search queue look before they store
         if (STATS) search_peak = ctl.count[Q_SEARCH] > search_peak ? ctl.count[Q_SEARCH] : search_peak;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
@@ -405,7 +429,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 // (in a launch of several frames a pixel may have to wait for its previous frame's store: back into the queue)
                 const bool ended = got && end_pixel_item<BATCH>(fa, ps);
                 const bool started = take_pixels<BATCH>(L, fa, cold_base, ended, i);
-                queue_push(L, Q_SEARCH, started, i);  // kind 0: the next pixel's first ray
+                queue_push(L, Q_SEARCH, started, i, crowded);  // kind 0: the next pixel's first ray
                 if (BATCH) {
                     queue_push(L, Q_PIXEL, got && !ended, i);
                     // the pixels that wait must not keep this wave from the other queues (the fullest queue is served
@@ -414,7 +438,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 }
             } else if (q == Q_END) {
                 if (got) end_sample_item(fa, ps);
-                queue_push(L, Q_SEARCH, got, i);  // kind 0: the next sample's first ray
+                queue_push(L, Q_SEARCH, got, i, crowded);  // kind 0: the next sample's first ray
             } else if (q == Q_LIT) {
                 if (got) lit_item(sc, ps);
                 queue_push_any<(1u << Q_END) | (1u << Q_PIXEL)>(L, got ? end_queue(ps, 0u) : -1, i);
@@ -425,7 +449,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 // entry says whether it was a sample's first ray)
                 if (got) ends = shade_item(sc, fa, ps, recs, q == Q_MISS ? (int)(item >> 12) : q - Q_FIRST, light_kind, retry);
                 // a first hit may send a light query on its way beside the path
-                if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12));
+                if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12), crowded);
                 // the path: its next ray, or its end - where the sample waits for its light query if that is still
                 // out (whoever of the two comes last queues the sample's end)
                 int to = -1;
@@ -440,7 +464,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     if (f & LF_PENDING) { f = ps.or_flags(LF_PATH_DONE); last = (f & LF_DONE) != 0u; }
                     if (last) to = end_queue(ps, f);
                 }
-                queue_push_any<(1u << Q_SEARCH) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry);
+                queue_push_any<(1u << Q_SEARCH) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry, crowded);
                 // items put back (they wait for their light query to be taken by a lane or, with the per-pixel hash,
                 // to report its hit id) must not keep the waves from the searching that would end the wait
                 search_first = __ballot(got && retry) != 0ull;
