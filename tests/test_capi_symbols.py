@@ -44,3 +44,22 @@ def test_defaults_and_errors_without_gpu():
     assert lib.rt_abi_version() == 1
     assert lib.rt_render_frame(None, None, None, None) == capi.RT_ERR_INVALID_ARGUMENT
     assert lib.rt_scene_create(99, None, C.byref(C.c_void_p())) == capi.RT_ERR_INVALID_ARGUMENT
+
+
+def test_ctypes_structs_have_the_headers_sizes(tmp_path):
+    """Every struct the library reads or fills through a pointer must have the size the C compiler gives it from
+    include/rt_abi.h: a field added on one side only would make the library write past a Python-side buffer."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "a C compiler is part of the build environment"
+    names = ["RtSphere", "RtMaterial", "RtLight", "RtTriangle", "RtVertex", "RtMeshInfo", "RtCamera", "RtPushConstants",
+             "RtParams", "RtStats", "RtSceneView", "RtControllerState"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rt_abi.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run([cc, "-std=c99", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in names:
+        assert C.sizeof(getattr(capi, n)) == int(out[n]), f"{n}: ctypes {C.sizeof(getattr(capi, n))} bytes, header {out[n]}"
