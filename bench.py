@@ -91,6 +91,11 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks on however many GPUs there are (rank r renders on GPU r mod count; RCCL wants one GPU per "
+                         "rank, so the ranks talk over gloo through host memory), and rank 0 checks the completed frame bit for "
+                         "bit against the same frames rendered whole on its GPU: the N-rank path of this script on a one-GPU box; "
+                         "timings mean nothing")
     args = ap.parse_args()
     # stdout carries ONE line, the result; whatever the libraries print there meanwhile (RCCL announces its version
     # on stdout) goes to stderr: file descriptor 1 is pointed at 2 until the line is written
@@ -105,13 +110,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
+    if args.rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = world > 1 or args.force_collective
     if collective:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    small = torch.device("cpu") if args.rehearse else dev  # where the few scalars exchanged at the end live
 
     preset, W, H, spp, max_bounces, desc = WORKLOADS[args.workload]
     accel = capi.RT_ACCEL_BVH if args.accel == "bvh" else capi.RT_ACCEL_FLAT
@@ -137,7 +148,8 @@ def main() -> None:
     if collective and partition == "strips":
         # one all-gather per frame: colours + counts of own rows packed by the library (20 B per pixel), the
         # other ranks' rows unpacked and their BGRA8 bytes rebuilt by it
-        exchange = parallel.PackedStripExchange(acc, cnt, bgra, STRIP_ROWS, world, rank, ctx=ctx, include_self=args.force_collective)
+        exchange = parallel.PackedStripExchange(acc, cnt, bgra, STRIP_ROWS, world, rank, ctx=ctx, include_self=args.force_collective,
+                                                via_host=args.rehearse)
     packed, gathered = torch.cuda.Event(), torch.cuda.Event()
     pending = [False]  # a gathered frame still waits to be unpacked
 
@@ -214,9 +226,9 @@ def main() -> None:
     own_frames = len(parallel.frames_of(FRAMES_PER_BATCH, world, rank)) if partition == "samples" else fpl
     kernel_ms = [a.elapsed_time(b) / max(1, own_frames) for a, b in events]  # per frame (a launch may hold several)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
-    kern = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=small)
+    total_rays = torch.tensor([float(rays)], dtype=torch.float64, device=small)
+    kern = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=small)
     if collective:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_rays, op=dist.ReduceOp.SUM)
@@ -224,6 +236,26 @@ def main() -> None:
     elapsed_s = float(elapsed.item())
     job_rays = float(total_rays.item())
     avg_kernel_ms = float(kern.item())
+
+    if args.rehearse and partition == "strips":
+        # the frame the ranks completed together against the same frames rendered whole by one context
+        frames_done = (SETTLE + args.warmup + args.steps) * fpl
+        mine = (acc.clone(), cnt.clone(), bgra.clone())
+        if rank == 0:
+            whole = Context(local_rank)
+            whole.upload_scene(scene)
+            whole.resize(W, H)
+            whole_params = make_params(spp, max_bounces, accel, 0, 1, 0, pipe_flags)
+            for f in range(0, frames_done, fpl):
+                whole.render_frames(cam, [scene.push_constants(0.0, f + k, f + k == 0) for k in range(fpl)], whole_params)
+            wa, wc = whole.read_accum()
+            wb = whole.read_bgra8()
+            same = (bool((mine[0].cpu().numpy().view("uint32") == wa.view("uint32")).all()) and bool((mine[1].cpu().numpy() == wc).all())
+                    and bool((mine[2].cpu().numpy().view("uint8").reshape(H, W, 4) == wb).all()))
+            print(f"rehearsal: {world} ranks, {frames_done} frames, completed frame bit-identical to one context's: {same}", file=sys.stderr)
+            whole.close()
+            if not same:
+                raise SystemExit("rehearsal failed: the frame completed by the ranks differs from the one rendered whole")
 
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
     pipeline = {capi.RT_PIPELINE_SINGLE: "single", capi.RT_PIPELINE_POOLED: "pooled"}[ctx.stats().pipeline]  # what the timed frames ran on

@@ -132,10 +132,11 @@ class PackedStripExchange:
     restatements above (CPU rehearsals with gloo)."""
 
     def __init__(self, acc: torch.Tensor, cnt: torch.Tensor, bgra: torch.Tensor, strip_rows: int, world: int, rank: int,
-                 ctx=None, group: Optional[dist.ProcessGroup] = None, include_self: bool = False):
+                 ctx=None, group: Optional[dist.ProcessGroup] = None, include_self: bool = False, via_host: bool = False):
         self.acc, self.cnt, self.bgra = acc, cnt, bgra
         self.strip_rows, self.world, self.rank, self.ctx, self.group = strip_rows, world, rank, ctx, group
         self.skip = -1 if include_self else rank
+        self.via_host = via_host  # device buffers, but a backend that gathers host memory (rehearsals over gloo)
         height, width = cnt.shape
         self.bytes = staging_bytes(height, width, strip_rows, world)
         self.send = torch.zeros(self.bytes, dtype=torch.uint8, device=acc.device)
@@ -150,6 +151,12 @@ class PackedStripExchange:
 
     def gather(self) -> None:
         """The one collective (torch's current stream)."""
+        if self.via_host:
+            torch.cuda.current_stream(self.send.device).synchronize()  # (the caller made this stream wait for the packing)
+            parts = [torch.empty(self.bytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, self.send.cpu(), group=self.group)
+            self.recv.copy_(torch.cat(parts))
+            return
         dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
     def unpack(self) -> None:
