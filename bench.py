@@ -166,7 +166,7 @@ def main() -> None:
                 ev[1].record(rt_stream)
             if collective:
                 main_stream.wait_stream(rt_stream)
-                parallel.reduce_samples(acc, cnt)
+                parallel.reduce_samples(acc, cnt, via_host=args.rehearse)
                 rt_stream.wait_stream(main_stream)
             ctx.resolve()
             return

@@ -191,8 +191,15 @@ def frames_of(n_frames: int, world: int, rank: int) -> List[int]:
     return [f for f in range(n_frames) if f % world == rank]
 
 
-def reduce_samples(accum: torch.Tensor, counts: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
-    """Sum the per-rank accumulation buffers in place on every rank."""
+def reduce_samples(accum: torch.Tensor, counts: torch.Tensor, group: Optional[dist.ProcessGroup] = None, via_host: bool = False) -> None:
+    """Sum the per-rank accumulation buffers in place on every rank.  `via_host`: device buffers, but a backend that
+    reduces host memory (rehearsals over gloo)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if via_host:
+            for t in (accum, counts):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+            return
         dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
