@@ -298,7 +298,8 @@ enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once t
        RT_OPT_BVH_MAX_LEAF = 7,   /* most primitives per BVH leaf (1..8, 4)                                                  */
        RT_OPT_POOL_SLOTS = 8,     /* pooled kernel: paths in flight per workgroup (0 = chosen by scene size, ..1392)         */
        RT_OPT_BVH_TREELET = 9,    /* BVH node layout: levels per treelet (0 / 1 = depth-first order, ..16); next upload      */
-       RT_OPT_BVH_WIDTH = 10 };   /* pooled kernel: children per node of the tree it walks (2, 4; 0 = 4 when its stack fits) */
+       RT_OPT_BVH_WIDTH = 10,     /* pooled kernel: children per node of the tree it walks (2, 4; 0 = 4 when its stack fits) */
+       RT_OPT_POOL_SHADER_WAVES = 11 }; /* pooled kernel: waves of a workgroup's 16 that only shade (1..8; 9 = none; 0 = by scene) */
 int rt_set_option(RtContext* ctx, int option, int value);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);

@@ -42,6 +42,7 @@ RT_PIPELINE_SINGLE, RT_PIPELINE_POOLED = 0, 2
 RT_GROUP_STRIPS, RT_GROUP_SAMPLES = 0, 1
 RT_OPT_EXIT_QUOTA_PCT, RT_OPT_REFILL_MIN, RT_OPT_POOL_BURST, RT_OPT_POOL_JOB_MIN = 1, 2, 3, 4
 RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF, RT_OPT_POOL_SLOTS, RT_OPT_BVH_TREELET, RT_OPT_BVH_WIDTH = 5, 6, 7, 8, 9, 10
+RT_OPT_POOL_SHADER_WAVES = 11
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1

@@ -116,7 +116,7 @@ int pool_threads_per_block();
 // per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid)
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream);
+                       int refill_min, int burst, int job_min, int slots_cap, int shader_waves, hipStream_t stream);
 // How many XCDs a grid of one workgroup per CU is spread over (the hardware's XCC_ID of every workgroup, read
 // back): their ids must be 0 .. n - 1, each with at least one workgroup; *n_xcds = 0 if that does not hold or
 // n > kXcds.  Synchronous; `scratch`: cu_count words of device memory.

@@ -54,6 +54,8 @@ constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the
 enum { kLive = 7 };  // PoolLds::hc[kLive]: the live count and the abort bit
 enum { Q_SEARCH = 0, Q_FIRST = 1, Q_NEXT = 2, Q_END = 3, Q_LIT = 4, Q_PIXEL = 5, Q_MISS = 6, kQueues = 7 };
 constexpr int kJobPriority = 2;         // s_setprio level of a wave inside a shading job (0 elsewhere)
+constexpr uint32_t kBacklog = 128;      // entries in a shading queue from which a searching wave helps the shading waves out
+constexpr int kShaderHold = 512;        // polls for which a shading wave leaves the pixel-end queue alone after a pixel had to wait
 constexpr uint32_t kChunk = 256;        // pixel slots a workgroup reserves per global atomic
 constexpr uint16_t kEmpty = 0xffffu;
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -340,7 +342,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
 
 template <int ACCEL, bool STATS, bool BATCH>
 __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
-                                                         int burst, int job_min, int slots_cap) {
+                                                         int burst, int job_min, int slots_cap, int shader_waves) {
     __shared__ PoolLds L;
     extern __shared__ uint32_t s_stack[];  // [kShortStack][kThreads]
     const int tid = (int)threadIdx.x;
@@ -415,7 +417,17 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
         // pixels than slots) a sixteenth of the live paths must do, or they would wait for each other
         uint32_t job_thresh = ctl.live >> 4;
         job_thresh = job_thresh < 1u ? 1u : (job_thresh > (uint32_t)job_min ? (uint32_t)job_min : job_thresh);
-        if (!search_first && (best >= job_thresh || (nothing_to_search && best != 0u))) {
+        // The workgroup's first `shader_waves` waves only shade: they take every full job the moment it is there (a
+        // searching wave comes by once per burst of steps, and while it shades the rays in its lanes stand still), hold
+        // no rays, and sleep between looks.  The other waves search; they shade what piles up (a queue of kBacklog
+        // entries) and, as always, whatever there is when they have nothing to search, so that jobs smaller than a
+        // wave are still done by whoever runs out of rays.  How many: about the share of the wave cycles that is
+        // shading (a quarter on the scenes that fit the caches, a tenth on the 1.07 M-triangle scene) times the
+        // workgroup's waves; the host chooses (pool_shader_waves in rt_api.hip).
+        const bool shader_wave = wave < shader_waves;
+        const bool take_job = shader_wave ? best >= job_thresh
+                                          : ((best >= job_thresh && (shader_waves == 0 || best >= kBacklog)) || (nothing_to_search && best != 0u));
+        if (!search_first && take_job) {
             uint32_t item = 0;
             bool got;
             const unsigned long long t_job = STATS ? __builtin_readcyclecounter() : 0ull;
@@ -443,7 +455,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     queue_push(L, Q_PIXEL, got && !ended, i);
                     // the pixels that wait must not keep this wave from the other queues (the fullest queue is served
                     // first, and a queue of waiting pixels stays full): it looks away from this one for a while
-                    if (__ballot(got && !ended) != 0ull) { search_first = true; pixel_hold = 16; }
+                    // (a round of a shading wave is a poll and a short sleep, not a burst of search steps: it stays away for longer)
+                    if (__ballot(got && !ended) != 0ull) { search_first = true; pixel_hold = shader_wave ? kShaderHold : 16; }
                 }
             } else if (q == Q_END) {
                 if (got) end_sample_item(fa, ps);
@@ -483,6 +496,12 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             continue;
         }
         search_first = false;
+        if (shader_wave) {  // nothing to shade right now
+            if ((lds_peek(&L.hc[kLive]) & 0x7fffffffu) == 0u) break;
+            if (++guard > kGuardLimit) { atomicOr(&L.hc[kLive], 0x80000000u); break; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
 
         // ---- search: retire the lanes whose ray has ended, hand them the next waiting rays
         const unsigned long long t_search = STATS ? __builtin_readcyclecounter() : 0ull;
@@ -621,7 +640,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     }
 }
 
-typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int);
+typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int, int);
 template <bool BATCH>
 PoolKernel pick_kernel_of(int accel, bool stats) {
     if (accel == 2) return stats ? pool_kernel<2, true, BATCH> : pool_kernel<2, false, BATCH>;
@@ -653,10 +672,11 @@ hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, i
 }
 
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
-                       int refill_min, int burst, int job_min, int slots_cap, hipStream_t stream) {
+                       int refill_min, int burst, int job_min, int slots_cap, int shader_waves, hipStream_t stream) {
     if (grid == 0) return hipSuccess;
+    shader_waves = shader_waves < 0 ? 0 : (shader_waves > kWaves / 2 ? kWaves / 2 : shader_waves);  // searching waves there must be
     slots_cap = (slots_cap <= 0 || slots_cap > kPool) ? kPool : (slots_cap < kWaves ? kWaves : slots_cap / kWaves * kWaves);
-    hipLaunchKernelGGL(pick_kernel(accel, stats, fa.n_frames > 1), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap);
+    hipLaunchKernelGGL(pick_kernel(accel, stats, fa.n_frames > 1), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap, shader_waves);
     return hipGetLastError();
 }
 

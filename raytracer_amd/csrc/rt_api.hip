@@ -199,7 +199,7 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
         {"RT_EXIT_QUOTA_PCT", RT_OPT_EXIT_QUOTA_PCT}, {"RT_REFILL_MIN", RT_OPT_REFILL_MIN}, {"RT_POOL_BURST", RT_OPT_POOL_BURST},
         {"RT_POOL_JOB_MIN", RT_OPT_POOL_JOB_MIN}, {"RT_TILE_CLASSES", RT_OPT_TILE_CLASSES}, {"RT_POOL_PER_CU", RT_OPT_POOL_PER_CU},
         {"RT_MAX_LEAF", RT_OPT_BVH_MAX_LEAF}, {"RT_POOL_SLOTS", RT_OPT_POOL_SLOTS}, {"RT_BVH_TREELET", RT_OPT_BVH_TREELET},
-        {"RT_BVH_WIDTH", RT_OPT_BVH_WIDTH}};
+        {"RT_BVH_WIDTH", RT_OPT_BVH_WIDTH}, {"RT_POOL_SHADER_WAVES", RT_OPT_POOL_SHADER_WAVES}};
     for (const auto& e : env)
         if (const char* v = getenv(e.name)) (void)rt_set_option(c, e.option, atoi(v));  // out-of-range values are ignored
     *out_ctx = c;
@@ -467,6 +467,17 @@ static int pool_burst(const RtContext* c, int width) {
     const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
     return (width == 4 && scene_bytes <= ((size_t)16 << 20)) ? 8 : 16;
 }
+// Waves of a pooled workgroup (of 16) that only shade.  About the share of the wave cycles that is shading: the scenes
+// that fit the caches spend a quarter of them there (1080p, per frame: teapot scene 6.94 -> 6.77 ms with three such waves,
+// star scene 2.26 -> 2.22, an eighth of the teapot frame 3.33 -> 3.13; fused launches 6.74 -> 6.68 and 1.95 -> 1.93 with
+// four, an eighth 1.33 -> 1.14), the 1.07 M-triangle scene a tenth (two waves: 11.61 -> 11.28, fused 9.83 -> 9.49; four
+// cost it 3 %).
+static int pool_shader_waves(const RtContext* c, int n_frames) {
+    if (c->opt.pool_shader_waves > 0) return c->opt.pool_shader_waves >= 9 ? 0 : c->opt.pool_shader_waves;
+    const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
+    if (scene_bytes > ((size_t)16 << 20)) return 2;
+    return n_frames > 1 ? 4 : 3;
+}
 // Stack overflow words per lane the pooled kernel is given by rt_render_frame (which may allocate).
 static int pooled_overflow_words(const RtContext* c) {
     if (c->opt.bvh_width == 2 || c->wide_nodes <= 0) return rtd::pool_overflow_per_lane();
@@ -494,7 +505,7 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
             }
             c->last_width = p.accel == RT_ACCEL_BVH ? width : 0;
             RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c, fa.n_frames),
-                                       c->stream));
+                                       pool_shader_waves(c, fa.n_frames), c->stream));
         } else {
             // the single kernel keeps a stack of rtd::kStackDepth entries per lane in LDS: the wide tree where that holds it
             rtd::DeviceScene sc = sc_in;
@@ -753,7 +764,8 @@ int rt_set_option(RtContext* c, int option, int value) {
         {RT_OPT_POOL_BURST, &c->opt.pool_burst, 0, 1024},        {RT_OPT_POOL_JOB_MIN, &c->opt.pool_job_min, 1, 64},
         {RT_OPT_TILE_CLASSES, &c->opt.tile_classes, 1, 64},      {RT_OPT_POOL_PER_CU, &c->opt.pool_per_cu, 0, 8},
         {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8},       {RT_OPT_POOL_SLOTS, &c->opt.pool_slots, 0, 4096},
-        {RT_OPT_BVH_TREELET, &c->opt.bvh_treelet, 0, 16},        {RT_OPT_BVH_WIDTH, &c->opt.bvh_width, 0, 4}};
+        {RT_OPT_BVH_TREELET, &c->opt.bvh_treelet, 0, 16},        {RT_OPT_BVH_WIDTH, &c->opt.bvh_width, 0, 4},
+        {RT_OPT_POOL_SHADER_WAVES, &c->opt.pool_shader_waves, 0, 9}};
     for (const auto& t : table) {
         if (t.option != option) continue;
         if (value < t.lo || value > t.hi || (option == RT_OPT_BVH_WIDTH && (value == 1 || value == 3)))

@@ -16,6 +16,7 @@ struct RtOptions {
     int pool_burst = 0;       // pooled kernel: search steps between two looks at the queues (0: the library's choice by tree and scene size)
     int pool_job_min = 64;    // pooled kernel: queue entries that make a shading job
     int pool_slots = 0;       // pooled kernel: paths in flight per workgroup (0: the library's choice by scene size)
+    int pool_shader_waves = 0;  // pooled kernel: waves per workgroup that only shade (0: the library's choice by scene size; 9: none)
     int tile_classes = 16;    // cost classes of the frame-to-frame tile order
     int pool_per_cu = 0;      // pooled kernel: cap on workgroups per CU (0: what fits)
     int bvh_max_leaf = 4;     // builder: most primitives per leaf (takes effect at the next rt_upload_scene)
