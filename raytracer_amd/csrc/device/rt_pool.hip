@@ -340,9 +340,12 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
     return started;  // the caller queues these slots for the search
 }
 
-template <int ACCEL, bool STATS, bool BATCH>
+// NSW: the number of shading waves as a compile-time constant (the instances the host's own choices run on: 1 % on a
+// single frame of the teapot scene), or 0 for the kernel argument.
+template <int ACCEL, bool STATS, bool BATCH, int NSW = 0>
 __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(const DeviceScene sc, const FrameArgs fa, const PathPool pp, int refill_min,
-                                                         int burst, int job_min, int slots_cap, int shader_waves) {
+                                                         int burst, int job_min, int slots_cap, int shader_waves_arg) {
+    const int shader_waves = NSW > 0 ? NSW : shader_waves_arg;
     __shared__ PoolLds L;
     extern __shared__ uint32_t s_stack[];  // [kShortStack][kThreads]
     const int tid = (int)threadIdx.x;
@@ -646,7 +649,15 @@ PoolKernel pick_kernel_of(int accel, bool stats) {
     if (accel == 2) return stats ? pool_kernel<2, true, BATCH> : pool_kernel<2, false, BATCH>;
     return accel == 1 ? (stats ? pool_kernel<1, true, BATCH> : pool_kernel<1, false, BATCH>) : (stats ? pool_kernel<0, true, BATCH> : pool_kernel<0, false, BATCH>);
 }
-PoolKernel pick_kernel(int accel, bool stats, bool batch = false) { return batch ? pick_kernel_of<true>(accel, stats) : pick_kernel_of<false>(accel, stats); }
+PoolKernel pick_kernel(int accel, bool stats, bool batch = false, int shader_waves = 0) {
+    if (accel == 2 && !stats) {  // the instances with the shading waves compiled in
+        if (!batch && shader_waves == 3) return pool_kernel<2, false, false, 3>;
+        if (!batch && shader_waves == 2) return pool_kernel<2, false, false, 2>;
+        if (batch && shader_waves == 4) return pool_kernel<2, false, true, 4>;
+        if (batch && shader_waves == 2) return pool_kernel<2, false, true, 2>;
+    }
+    return batch ? pick_kernel_of<true>(accel, stats) : pick_kernel_of<false>(accel, stats);
+}
 constexpr size_t kStackLds = (size_t)kShortStack * kThreads * sizeof(uint32_t);
 
 }  // namespace
@@ -676,7 +687,7 @@ hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPoo
     if (grid == 0) return hipSuccess;
     shader_waves = shader_waves < 0 ? 0 : (shader_waves > kWaves / 2 ? kWaves / 2 : shader_waves);  // searching waves there must be
     slots_cap = (slots_cap <= 0 || slots_cap > kPool) ? kPool : (slots_cap < kWaves ? kWaves : slots_cap / kWaves * kWaves);
-    hipLaunchKernelGGL(pick_kernel(accel, stats, fa.n_frames > 1), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap, shader_waves);
+    hipLaunchKernelGGL(pick_kernel(accel, stats, fa.n_frames > 1, shader_waves), dim3(grid), dim3(kThreads), kStackLds, stream, sc, fa, pp, refill_min, burst, job_min, slots_cap, shader_waves);
     return hipGetLastError();
 }
 
