@@ -13,13 +13,13 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_c3 --output-form
 cp $out/prof_c3/*/*kernel_stats.csv $out/c3_kernel_stats.csv
 # counters per FRAME: one frame per launch (the bench's default hands the library 8 frames per launch; that kernel follows)
 BENCH_ARGS="--pipeline pooled --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c3_pooled || exit 1
-python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<2, false, false>" 1 > $out/c3_pooled_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<2, false, false" 1 > $out/c3_pooled_pmc.txt
 BENCH_ARGS="--pipeline pooled --frames-per-launch 8" bash tools/pmc_passes.sh $out/pmc_c3_fused || exit 1
-python3 tools/pmc_summary.py $out/pmc_c3_fused "pool_kernel<2, false, true>" 1 > $out/c3_pooled_fused8_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c3_fused "pool_kernel<2, false, true" 1 > $out/c3_pooled_fused8_pmc.txt
 BENCH_ARGS="--pipeline single --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c3_single || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_single "render_kernel<2, false>" 1 > $out/c3_single_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline pooled --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c5_pooled || exit 1
-python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<2, false, false>" 1 > $out/c5_pooled_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<2, false, false" 1 > $out/c5_pooled_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline single --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c5_single || exit 1
 python3 tools/pmc_summary.py $out/pmc_c5_single "render_kernel<1, false>" 1 > $out/c5_single_pmc.txt
 cat $out/bench_c3.json; head -4 $out/c3_kernel_stats.csv | cut -c1-160
