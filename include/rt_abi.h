@@ -292,7 +292,7 @@ int rt_get_stats(RtContext* ctx, RtStats* out);
 enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once this % of busy lanes have a result (1..100, 75) */
        RT_OPT_REFILL_MIN = 2,     /* pooled kernel: idle lanes of a searching wave before it fetches new rays (1..64, 16)      */
        RT_OPT_POOL_BURST = 3,     /* pooled kernel: search steps between two looks at the queues (0 = by scene size, ..1024)   */
-       RT_OPT_POOL_JOB_MIN = 4,   /* pooled kernel: queue entries that make a shading job (1..64, 64)                        */
+       RT_OPT_POOL_JOB_MIN = 4,   /* pooled kernel: queue entries that make a shading job (1..64; 0 = by scene size)         */
        RT_OPT_TILE_CLASSES = 5,   /* cost classes of the frame-to-frame tile order (1..64, 16)                               */
        RT_OPT_POOL_PER_CU = 6,    /* pooled kernel: cap on workgroups per CU (0 = what fits, ..8)                            */
        RT_OPT_BVH_MAX_LEAF = 7,   /* most primitives per BVH leaf (1..8, 4)                                                  */

@@ -478,6 +478,17 @@ static int pool_shader_waves(const RtContext* c, int n_frames) {
     if (scene_bytes > ((size_t)16 << 20)) return 2;
     return n_frames > 1 ? 4 : 3;
 }
+// Queue entries that make a shading job.  A full wave's worth was best while every wave both searched and shaded (a
+// job of 48 cost the teapot frame 1 %, one of 40 3 %); a wave that only shades loses nothing by starting early: with
+// shading waves 48 is worth 0.3 % on the scenes that fit the caches (32 / 40 / 48 / 64: 6.76 / 6.76 / 6.77 / 6.78 ms, 4K frames
+// 7.82 / 7.82 / 7.82 / 7.85), and the 1.07 M-triangle scene, whose searches are long and whose queues fill slowly, takes
+// 11.19 / 11.26 / 11.30 / 11.33 ms.
+static int pool_job_min(const RtContext* c, int n_frames) {
+    if (c->opt.pool_job_min > 0) return c->opt.pool_job_min;
+    if (pool_shader_waves(c, n_frames) == 0) return 64;
+    const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
+    return scene_bytes > ((size_t)16 << 20) ? 32 : 48;
+}
 // Stack overflow words per lane the pooled kernel is given by rt_render_frame (which may allocate).
 static int pooled_overflow_words(const RtContext* c) {
     if (c->opt.bvh_width == 2 || c->wide_nodes <= 0) return rtd::pool_overflow_per_lane();
@@ -504,7 +515,7 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
                 sc.nodes = (const float4*)c->d_nodes_wide;
             }
             c->last_width = p.accel == RT_ACCEL_BVH ? width : 0;
-            RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), c->opt.pool_job_min, pool_slots(c, fa.n_frames),
+            RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), pool_job_min(c, fa.n_frames), pool_slots(c, fa.n_frames),
                                        pool_shader_waves(c, fa.n_frames), c->stream));
         } else {
             // the single kernel keeps a stack of rtd::kStackDepth entries per lane in LDS: the wide tree where that holds it
@@ -761,7 +772,7 @@ int rt_set_option(RtContext* c, int option, int value) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     struct { int option; int* field; int lo, hi; } table[] = {
         {RT_OPT_EXIT_QUOTA_PCT, &c->opt.exit_quota_pct, 1, 100}, {RT_OPT_REFILL_MIN, &c->opt.refill_min, 1, 64},
-        {RT_OPT_POOL_BURST, &c->opt.pool_burst, 0, 1024},        {RT_OPT_POOL_JOB_MIN, &c->opt.pool_job_min, 1, 64},
+        {RT_OPT_POOL_BURST, &c->opt.pool_burst, 0, 1024},        {RT_OPT_POOL_JOB_MIN, &c->opt.pool_job_min, 0, 64},
         {RT_OPT_TILE_CLASSES, &c->opt.tile_classes, 1, 64},      {RT_OPT_POOL_PER_CU, &c->opt.pool_per_cu, 0, 8},
         {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8},       {RT_OPT_POOL_SLOTS, &c->opt.pool_slots, 0, 4096},
         {RT_OPT_BVH_TREELET, &c->opt.bvh_treelet, 0, 16},        {RT_OPT_BVH_WIDTH, &c->opt.bvh_width, 0, 4},

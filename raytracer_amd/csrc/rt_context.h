@@ -14,7 +14,7 @@ struct RtOptions {
     int exit_quota_pct = 75;  // single kernel: the search loop returns once this share of the busy lanes has a result
     int refill_min = 16;      // pooled kernel: idle lanes of a searching wave before it fetches new rays
     int pool_burst = 0;       // pooled kernel: search steps between two looks at the queues (0: the library's choice by tree and scene size)
-    int pool_job_min = 64;    // pooled kernel: queue entries that make a shading job
+    int pool_job_min = 0;     // pooled kernel: queue entries that make a shading job (0: the library's choice by scene size)
     int pool_slots = 0;       // pooled kernel: paths in flight per workgroup (0: the library's choice by scene size)
     int pool_shader_waves = 0;  // pooled kernel: waves per workgroup that only shade (0: the library's choice by scene size; 9: none)
     int tile_classes = 16;    // cost classes of the frame-to-frame tile order
