@@ -527,3 +527,27 @@ def test_pooled_queues_when_every_ray_ends_at_once(ctx, kind):
     ctx.render_frame(cam, s.push_constants(0.0, 2, False), make_params(4, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED | capi.RT_FLAG_TRAVERSAL_STATS))
     st = ctx.stats()
     assert 0 < st.search_queue_peak <= st.search_queue_size * 7 // 8, (st.search_queue_peak, st.search_queue_size)
+
+
+def test_shading_waves_change_the_schedule_only(ctx, teapot):
+    """RT_OPT_POOL_SHADER_WAVES: however many of a workgroup's waves only shade (none, one, five, the most the kernel
+    accepts; the default runs on kernel instances of their own), and however small a shading job may be, the pooled
+    kernel's outputs are the same bits - single frames and a fused launch."""
+    W, H = 480, 270
+    ref = gpu_frames(ctx, teapot, W, H, spp=3, max_bounces=4, frames=2, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+    cam = default_camera(W, H)
+    pcs = [teapot.push_constants(0.0, f, f == 0) for f in range(4)]
+    ctx.render_frames(cam, pcs, make_params(3, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED))
+    fused_ref = ctx.read_accum()[0].copy()
+    try:
+        for waves, job in ((9, 64), (1, 16), (5, 48), (8, 1)):
+            ctx.set_option(capi.RT_OPT_POOL_SHADER_WAVES, waves)
+            ctx.set_option(capi.RT_OPT_POOL_JOB_MIN, job)
+            g = gpu_frames(ctx, teapot, W, H, spp=3, max_bounces=4, frames=2, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED, upload=False)
+            assert_identical(g, ref)
+            ctx.render_frames(cam, pcs, make_params(3, 4, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED))
+            assert ctx.stats().frames == 4
+            assert bit_equal_pixels(ctx.read_accum()[0], fused_ref).all(), (waves, job)
+    finally:
+        ctx.set_option(capi.RT_OPT_POOL_SHADER_WAVES, 0)
+        ctx.set_option(capi.RT_OPT_POOL_JOB_MIN, 0)
