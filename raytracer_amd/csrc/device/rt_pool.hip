@@ -1,5 +1,5 @@
 // rt_pool.hip — the pooled form of the path tracer for gfx950 (MI355X): one persistent
-// launch per frame in which every workgroup owns a pool of kPool path slots (1392 for its 1024 lanes),
+// launch per frame in which every workgroup owns a pool of kPool path slots (1344 for its 1024 lanes),
 // keeps their hot state in LDS and regroups them continuously through queues in LDS.
 //
 // One frame = one execution of shaders/raytracer.comp::main for every pixel this context
@@ -37,7 +37,7 @@ namespace {
 #define RT_POOL_THREADS 1024
 #endif
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 1392
+#define RT_POOL_SLOTS 1344
 #endif
 #ifndef RT_POOL_STACK
 #define RT_POOL_STACK 8
@@ -49,6 +49,7 @@ constexpr int kThreads = RT_POOL_THREADS;  // threads per workgroup: one workgro
 constexpr int kWaves = kThreads / 64;
 constexpr int kPool = RT_POOL_SLOTS;    // path slots per workgroup (multiple of kWaves, <= 4096)
 constexpr int kRing = kPool <= 256 ? 256 : kPool <= 512 ? 512 : kPool <= 1024 ? 1024 : kPool <= 2048 ? 2048 : 4096;  // queue ring size
+constexpr int kSearchRing = 2 * kRing;  // the search queue's ring: a slot can have two rays waiting (its path's and its light query's)
 constexpr int kShortStack = RT_POOL_STACK;  // traversal stack entries per lane kept in LDS
 constexpr int kOverflow = kStackDepth - kShortStack;  // entries per lane of the overflow area (a stack never holds more than kStackDepth)
 enum { kLive = 7 };  // PoolLds::hc[kLive]: the live count and the abort bit
@@ -70,7 +71,7 @@ struct PoolLds {
     int32_t hit_idx[kPool];
     uint32_t flags[(kPool + 3) / 4];  // one byte per slot: LF_* of the sample's light query (changed by LDS atomics on the word)
     // queues
-    uint16_t items[kQueues][kRing];  // rings; an entry is a slot index | kind << 12, kEmpty when free
+    uint16_t items[(kQueues + 1) * kRing];  // rings (ring_entry: the search queue's first, twice the size); an entry is a slot index | kind << 12, kEmpty when free
     // What every wave polls once per round, in one 32-byte block (two 16-byte LDS reads):
     // hc[q] = next ring position to pop << 16 | entries published and not yet claimed (one word, so
     // that a pop claims entries and advances the position with a single compare-and-swap), for the kQueues queues;
@@ -80,7 +81,12 @@ struct PoolLds {
     uint32_t res_lock, res_next, res_end;  // the workgroup's reserve of pixel slots of the frame (taken kChunk at a time)
 };
 static_assert(kQueues == 7 && kRing <= 65536 && 65536 % kRing == 0, "hc packs a 16-bit ring position and a 16-bit count");
-static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing, "a queue entry is a 12-bit slot index plus a kind, and a ring holds every slot");
+static_assert(kPool % kWaves == 0 && kPool <= 4096 && kPool <= kRing && 2 * kPool <= kSearchRing,
+              "a queue entry is a 12-bit slot index plus a kind, a ring holds every slot and the search queue's every ray there can be");
+// Where position `pos` of queue q's ring lies in PoolLds::items.
+RT_DEV uint32_t ring_entry(int q, uint32_t pos) {
+    return q == Q_SEARCH ? (pos & (uint32_t)(kSearchRing - 1)) : (uint32_t)(q + 1) * (uint32_t)kRing + (pos & (uint32_t)(kRing - 1));
+}
 static_assert(kThreads % 64 == 0 && kThreads <= 1024, "whole waves, one workgroup");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -159,25 +165,10 @@ RT_DEV PoolCtl poll_ctl(const PoolLds& L) {
     return c;
 }
 
-// The search queue may be asked for more places than its ring has: a slot can have two rays waiting (its path's
-// and its light query's), 2 * kPool > kRing, although the lanes hold most rays and the fullest it has been seen is
-// three quarters.  A pusher therefore never overwrites: a place that still holds an entry of the lap before is waited
-// for - its popper empties it - within the usual bound.  (The other queues hold one entry per slot at most.)  The wait's
-// LDS read is only paid when the wave's last look at the queues found the ring at least half full (`crowded`), which
-// covers a queue that fills up over several rounds; what it does not cover is a thousand rays pushed by the other
-// waves within one job of this wave onto a ring it saw half empty (from an empty ring, the start of a frame, all
-// sixteen waves' first-hit jobs together fill it exactly).  A ray that does get overwritten is not lost silently: its
-// pixel never ends, the bound on waiting trips and the frame is reported as abandoned.
-RT_DEV void wait_for_place(PoolLds& L, volatile lds_u16* e) {
-    uint32_t tries = 0;
-    while (*e != kEmpty && ++tries < kSpinLimit) __builtin_amdgcn_s_sleep(1);
-    if (tries >= kSpinLimit) atomicOr(&L.hc[kLive], 0x80000000u);
-}
-
 // Publish `item` for the lanes that ask.  Everything the wave stored before (path state in
 // LDS and device memory) is visible to the workgroup before an entry can be read: state stores,
 // release fence, entry store, count.
-RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item, bool crowded = false) {
+RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
     const int leader = __ffsll((long long)m) - 1;
@@ -188,11 +179,7 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item, bool crowded
     // Release BEFORE the entry store: entries are claimed by ring position, so another wave's count
     // may expose this position, and its popper takes the entry the moment it stops being kEmpty.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (want) {
-        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(pos + (uint32_t)__popcll(m & lanes_below())) & (kRing - 1)];
-        if (q == Q_SEARCH && crowded) wait_for_place(L, e);
-        *e = (uint16_t)item;
-    }
+    if (want) *(volatile lds_u16*)&L.items[ring_entry(q, pos + (uint32_t)__popcll(m & lanes_below()))] = (uint16_t)item;
     if (lane_id() == leader) atomicAdd(&L.hc[q], n);  // LDS operations of one wave complete in order: after the entries
 }
 
@@ -200,7 +187,7 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item, bool crowded
 // nothing) and its item; lane k reserves for queue k, so the wave pays one LDS atomic round trip
 // however many queues receive entries.  MASK: the queues this call site can name (the others cost nothing).
 template <unsigned MASK>
-RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item, bool crowded = false) {
+RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
     unsigned long long m[kQueues];
     unsigned long long any = 0ull;
 #pragma unroll
@@ -226,9 +213,10 @@ RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item, bool crowded = fals
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // before the entry store, as in queue_push
     if (q >= 0) {
-        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(base + (uint32_t)__popcll(mk & lanes_below())) & (kRing - 1)];
-        if (((MASK >> Q_SEARCH) & 1u) && crowded && q == Q_SEARCH) wait_for_place(L, e);
-        *e = (uint16_t)item;
+        const uint32_t at = base + (uint32_t)__popcll(mk & lanes_below());
+        // (a call site that cannot name the search queue needs no look at which ring it is)
+        const uint32_t idx = ((MASK >> Q_SEARCH) & 1u) ? ring_entry(q, at) : (uint32_t)(q + 1) * (uint32_t)kRing + (at & (uint32_t)(kRing - 1));
+        *(volatile lds_u16*)&L.items[idx] = (uint16_t)item;
     }
     if (lane < kQueues && n_mine != 0u) atomicAdd(&L.hc[lane], n_mine);
 }
@@ -256,7 +244,7 @@ RT_DEV uint32_t queue_pop(PoolLds& L, int q, unsigned long long takers, uint32_t
     if (n == 0u) return 0u;
     const uint32_t rank = (uint32_t)__popcll(takers & lanes_below());
     if (((takers >> lane_id()) & 1ull) && rank < n) {
-        volatile lds_u16* e = (volatile lds_u16*)&L.items[q][(pos + rank) & (kRing - 1)];
+        volatile lds_u16* e = (volatile lds_u16*)&L.items[ring_entry(q, pos + rank)];
         uint32_t v = *e, tries = 0;
         while (v == kEmpty && ++tries < kSpinLimit) v = *e;  // the pusher is between its reservation and its store
         if (v == kEmpty) atomicOr(&L.hc[kLive], 0x80000000u);
@@ -355,7 +343,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     const float4* __restrict__ recs = (ACCEL >= 1) ? sc.prims_bvh : sc.prims_flat;
     const ShortStack stack{(lds_u32*)(s_stack + tid), (glb_u32*)(pp.stack_overflow + ((size_t)blockIdx.x * kThreads + (size_t)tid) * pp.overflow_words), kShortStack, kThreads};
 
-    for (int i = tid; i < kQueues * kRing; i += kThreads) (&L.items[0][0])[i] = kEmpty;
+    for (int i = tid; i < (kQueues + 1) * kRing; i += kThreads) L.items[i] = kEmpty;
     if (tid < 8) L.hc[tid] = 0;
     if (tid < kQueues) L.tail[tid] = 0;
     // A frame with fewer pixels than the pools have slots is shared out evenly: every workgroup fills
@@ -402,7 +390,6 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     for (;;) {
         const PoolCtl ctl = poll_ctl(L);
         if (ctl.abort != 0u) break;
-        const bool crowded = ctl.count[Q_SEARCH] >= (uint32_t)(kRing / 2);  // pushes to the search queue look before they store
         if (STATS) search_peak = ctl.count[Q_SEARCH] > search_peak ? ctl.count[Q_SEARCH] : search_peak;
 
         // ---- a full wave of shading work of one kind?  (or any at all, when this wave has nothing to search)
@@ -453,7 +440,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 // (in a launch of several frames a pixel may have to wait for its previous frame's store: back into the queue)
                 const bool ended = got && end_pixel_item<BATCH>(fa, ps);
                 const bool started = take_pixels<BATCH>(L, fa, cold_base, ended, i);
-                queue_push(L, Q_SEARCH, started, i, crowded);  // kind 0: the next pixel's first ray
+                queue_push(L, Q_SEARCH, started, i);  // kind 0: the next pixel's first ray
                 if (BATCH) {
                     queue_push(L, Q_PIXEL, got && !ended, i);
                     // the pixels that wait must not keep this wave from the other queues (the fullest queue is served
@@ -463,7 +450,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 }
             } else if (q == Q_END) {
                 if (got) end_sample_item(fa, ps);
-                queue_push(L, Q_SEARCH, got, i, crowded);  // kind 0: the next sample's first ray
+                queue_push(L, Q_SEARCH, got, i);  // kind 0: the next sample's first ray
             } else if (q == Q_LIT) {
                 if (got) lit_item(sc, ps);
                 queue_push_any<(1u << Q_END) | (1u << Q_PIXEL)>(L, got ? end_queue(ps, 0u) : -1, i);
@@ -474,7 +461,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 // entry says whether it was a sample's first ray)
                 if (got) ends = shade_item(sc, fa, ps, recs, q == Q_MISS ? (int)(item >> 12) : q - Q_FIRST, light_kind, retry);
                 // a first hit may send a light query on its way beside the path
-                if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12), crowded);
+                if (q == Q_FIRST) queue_push(L, Q_SEARCH, got && light_kind != 0, i | ((uint32_t)light_kind << 12));
                 // the path: its next ray, or its end - where the sample waits for its light query if that is still
                 // out (whoever of the two comes last queues the sample's end)
                 int to = -1;
@@ -489,7 +476,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     if (f & LF_PENDING) { f = ps.or_flags(LF_PATH_DONE); last = (f & LF_DONE) != 0u; }
                     if (last) to = end_queue(ps, f);
                 }
-                queue_push_any<(1u << Q_SEARCH) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry, crowded);
+                queue_push_any<(1u << Q_SEARCH) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry);
                 // items put back (they wait for their light query to be taken by a lane or, with the per-pixel hash,
                 // to report its hit id) must not keep the waves from the searching that would end the wait
                 search_first = __ballot(got && retry) != 0ull;
@@ -635,7 +622,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 12), search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 42), step_cycles);
             atomicMax(fa.counters + 44, search_peak);
-            fa.counters[45] = (uint32_t)kRing;
+            fa.counters[45] = (uint32_t)kSearchRing;
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);
             for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)(fa.counters + 32 + 2 * k), job_cycles[k]);
         }

@@ -47,7 +47,7 @@ namespace {
 constexpr size_t kScratchTiles = 128u * 1024u;      // 8x8 tiles of the largest frame (8.39 M pixels, e.g. 3840 x 2184)
 constexpr size_t kScratchStampBytes = 256;          // 8 words: what the stored tile order was made for
 constexpr size_t kScratchAuxBytes = 192u << 10;     // work area of the tile order kernels (rtd::tile_order_aux_bytes() <= this)
-constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1392 x 64 B records + 1024 x 24 stack words), rounded up
+constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (up to 1392 x 64 B records + 1024 x 24 stack words), rounded up
 constexpr size_t kScratchBytes = kScratchStampBytes + kScratchAuxBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 192 KiB + 256 B
 constexpr int kMaxDevices = 64;
 }  // namespace
