@@ -360,6 +360,8 @@ def main() -> None:
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "avg_kernel_ms": avg_kernel_ms,
+                "per": (f"frame: the timed launch carries {launch_frames} frames, avg_kernel_ms is its measured duration / {launch_frames}; traffic, "
+                        "issued flops and the instruction counters come from PMC passes of one frame per launch") if launch_frames > 1 else "launch = frame",
                 "flops_per_ray": flops_per_ray,
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
