@@ -45,6 +45,51 @@ PEAK_VALU_TFLOPS_4CLK = 78.6
 PEAK_HBM_GBPS = 8000.0
 
 
+def lavapipe_probe() -> str:
+    """The baseline the metric names is the reference shader under Mesa lavapipe on the host cores: probe for what that
+    would take (a Vulkan loader, lavapipe's ICD manifest, a GLSL compiler) and say what is missing instead of failing."""
+    import ctypes.util
+    import glob
+    import shutil
+    missing = []
+    if not ctypes.util.find_library("vulkan") and not glob.glob("/usr/lib/*/libvulkan.so*") and not glob.glob("/usr/lib64/libvulkan.so*"):
+        missing.append("no libvulkan")
+    if not [m for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d", "/usr/local/share/vulkan/icd.d") for m in glob.glob(d + "/*lvp*")]:
+        missing.append("no lavapipe ICD")
+    if not (shutil.which("glslc") or shutil.which("glslangValidator")):
+        missing.append("no GLSL compiler")
+    if missing:
+        return "unavailable (" + ", ".join(missing) + " on this box)"
+    return "present but unused: this repository has no Vulkan harness for the reference shader"
+
+
+def gpu_same_config(device: int) -> dict:
+    """The CPU baseline's configuration (C1, same scene, camera, seeds) on the GPU, beside it: the flat search (the
+    reference's algorithm, what the CPU figure runs) and the tree search, kernel time of a frame launched alone,
+    median of five after three settling frames."""
+    preset, w, h, spp, mb, _ = WORKLOADS["c1"]
+    scene = Scene(preset)
+    ctx = Context(device)
+    out = {}
+    try:
+        ctx.upload_scene(scene)
+        ctx.resize(w, h)
+        cam = workload_camera("c1", w, h)
+        for name, accel in (("flat", capi.RT_ACCEL_FLAT), ("bvh", capi.RT_ACCEL_BVH)):
+            ms, rays = [], 0
+            for f in range(8):
+                ctx.render_frame(cam, scene.push_constants(0.0, 0, True), make_params(spp, mb, accel))
+                st = ctx.stats()
+                rays = st.rays
+                if f >= 3:
+                    ms.append(st.kernel_ms)
+            t = sorted(ms)[len(ms) // 2]
+            out[name] = {"ms_per_frame": t, "Mrays_per_s": rays / (t * 1e-3) / 1e6, "rays_per_frame": rays}
+    finally:
+        ctx.close()
+    return out
+
+
 def cpu_baseline() -> dict:
     """The CPU oracle (flat search = the reference's algorithm: every ray against every primitive) on
     BASELINE.json's CPU-runnable configuration C1 in full: Cornell box + teapot.glb, 640x360, 1 spp,
@@ -89,6 +134,9 @@ def main() -> None:
                          "fuses up to 16 into one launch; with several ranks the strips are exchanged once per step); "
                          "1 = one rt_render_frame call (and one exchange) per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the untimed check of the timed frames (rank 0 renders the same frames again, one per call, on the "
+                         "single kernel and compares colours, counts and BGRA8 bytes bit for bit)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the strip all-gather even with one rank (exercises the RCCL/stream path on one GPU)")
     ap.add_argument("--rehearse", action="store_true",
@@ -171,6 +219,10 @@ def main() -> None:
             ctx.resolve()
             return
         pc = scene.push_constants(0.0, frame * fpl, frame == 0)
+        if collective and args.force_collective:
+            # one rank unpacking its OWN rows too: the rows gathered after step N - 1 must land before kernel N adds to
+            # them (with several ranks a rank never unpacks rows it renders, and the unpack may follow the kernel)
+            flush()
         if ev is not None:
             ev[0].record(rt_stream)
         if fpl > 1:
@@ -237,41 +289,62 @@ def main() -> None:
     job_rays = float(total_rays.item())
     avg_kernel_ms = float(kern.item())
 
-    if args.rehearse and partition == "strips":
-        # the frame the ranks completed together against the same frames rendered whole by one context
-        frames_done = (SETTLE + args.warmup + args.steps) * fpl
+    # ---- untimed: are the frames just timed the right frames?  Rank 0 renders the same frames again, one rt_render_frame
+    # call each, whole, on the single kernel (another schedule of the per-path program, frame by frame instead of
+    # fused, unsplit instead of in strips) in a context of its own, and compares accumulated colours, sample counts and
+    # BGRA8 bytes bit for bit with what the timed path left in the framebuffer (strips: the frame all ranks completed
+    # together; samples: the last batch, summed over ranks - in another order than frame order, so within rounding there).
+    verified, verify_note = None, "skipped (--no-verify)"
+    frames_done = (SETTLE + args.warmup + args.steps) * frames_per_step
+    if not args.no_verify:
         mine = (acc.clone(), cnt.clone(), bgra.clone())
         if rank == 0:
             whole = Context(local_rank)
             whole.upload_scene(scene)
             whole.resize(W, H)
-            whole_params = make_params(spp, max_bounces, accel, 0, 1, 0, pipe_flags)
-            for f in range(0, frames_done, fpl):
-                whole.render_frames(cam, [scene.push_constants(0.0, f + k, f + k == 0) for k in range(fpl)], whole_params)
+            whole_params = make_params(spp, max_bounces, accel, 0, 1, 0, capi.RT_FLAG_SINGLE_KERNEL)
+            if partition == "samples":  # every step resets: what remains is the last batch
+                first = (SETTLE + args.warmup + args.steps - 1) * FRAMES_PER_BATCH
+                todo = [(first + f, f == 0) for f in range(FRAMES_PER_BATCH)]
+            else:
+                todo = [(f, f == 0) for f in range(frames_done)]
+            for f, reset in todo:
+                whole.render_frame(cam, scene.push_constants(0.0, f, reset), whole_params)
             wa, wc = whole.read_accum()
             wb = whole.read_bgra8()
-            same = (bool((mine[0].cpu().numpy().view("uint32") == wa.view("uint32")).all()) and bool((mine[1].cpu().numpy() == wc).all())
-                    and bool((mine[2].cpu().numpy().view("uint8").reshape(H, W, 4) == wb).all()))
-            print(f"rehearsal: {world} ranks, {frames_done} frames, completed frame bit-identical to one context's: {same}", file=sys.stderr)
             whole.close()
-            if not same:
-                raise SystemExit("rehearsal failed: the frame completed by the ranks differs from the one rendered whole")
+            ga, gc, gb = mine[0].cpu().numpy(), mine[1].cpu().numpy(), mine[2].cpu().numpy().view("uint8").reshape(H, W, 4)
+            counts_ok = bool((gc == wc).all()) and bool((gc == len(todo)).all())
+            if partition == "samples" and world > 1:
+                import numpy as np
+                verified = counts_ok and bool(np.allclose(ga, wa, rtol=1e-5, atol=1e-6))
+                verify_note = f"last batch of {len(todo)} frames summed over {world} ranks against the same frames accumulated in order on the single kernel: counts equal, colours within 1e-5 (the sum's order differs)"
+            else:
+                verified = counts_ok and bool((ga.view("uint32") == wa.view("uint32")).all()) and bool((gb == wb).all())
+                verify_note = (f"all {len(todo)} frames of the run ({SETTLE} settling + {args.warmup} warm-up + {args.steps} timed steps) rendered again one rt_render_frame "
+                               "call each, whole, on the single kernel: accumulated colours, counts and BGRA8 bytes bit-identical"
+                               if verified else "MISMATCH between the timed path's framebuffer and the same frames on the single kernel")
+            print(f"verify: {verify_note}: {verified}", file=sys.stderr)
 
     # traversal work per ray, from one extra (untimed) instrumented frame on this rank's rows
     pipeline = {capi.RT_PIPELINE_SINGLE: "single", capi.RT_PIPELINE_POOLED: "pooled"}[ctx.stats().pipeline]  # what the timed frames ran on
     launch_frames = ctx.stats().frames  # frames the library put into the last timed launch
     # what ONE frame costs when it is launched alone (the latency of a frame, where the steps above measure throughput):
     # kernel time of single rt_render_frame calls on this rank's rows, median of five
+    # (on the kernel the timed launches ran on: left to itself the library would time its two kernels against each other
+    # on these first single-frame calls of the configuration)
+    forced = capi.RT_FLAG_POOLED if pipeline == "pooled" else capi.RT_FLAG_SINGLE_KERNEL
+    alone = make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], forced)
     single_ms = []
     for k in range(5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(rt_stream)
-        ctx.render_frame(cam, scene.push_constants(0.0, 100000 + k, False), params)
+        ctx.render_frame(cam, scene.push_constants(0.0, 100000 + k, False), alone)
         b.record(rt_stream)
         ctx.sync()
         single_ms.append(a.elapsed_time(b))
     single_frame_ms = sorted(single_ms)[len(single_ms) // 2]
-    flags = capi.RT_FLAG_TRAVERSAL_STATS | pipe_flags
+    flags = capi.RT_FLAG_TRAVERSAL_STATS | forced
     pc = scene.push_constants(0.0, SETTLE + args.warmup, False)
     ctx.render_frame(cam, pc, make_params(spp, max_bounces, accel, strip[0], strip[1], strip[2], flags))
     st = ctx.stats()
@@ -373,14 +446,20 @@ def main() -> None:
                 **executed,
             },
         }
+        result["verified"] = verified
+        result["verified_note"] = verify_note
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"]["gpu_same_config"] = gpu_same_config(local_rank)
+            result["cpu_baseline"]["lavapipe"] = lavapipe_probe()
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
 
     ctx.close()
     if collective:
         dist.destroy_process_group()
+    if rank == 0 and verified is False:
+        raise SystemExit("bench.py: the timed frames differ from the same frames rendered one by one on the single kernel")
 
 
 if __name__ == "__main__":

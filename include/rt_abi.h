@@ -191,6 +191,9 @@ typedef struct RtStats {
                                    for a lane at once ...                                                            */
     int32_t  search_queue_size; /* ... and what that queue holds (a ray pushed beyond it would be lost, and the frame
                                    would fail with RT_ERR_HIP instead of finishing)                                  */
+    uint64_t stack_overflow_steps; /* pooled pipeline with TRAVERSAL_STATS: node visits that pushed onto a traversal stack
+                                      whose part in LDS was already full, i.e. whose entries went to the lane's overflow
+                                      area in device memory                                                          */
 } RtStats;
 
 typedef struct RtContext RtContext;
@@ -310,7 +313,13 @@ int rt_sync(RtContext* ctx);
 
 const char* rt_last_error(RtContext* ctx); /* ctx may be NULL: error of the calling thread's last failed rt_create */
 void rt_default_params(RtParams* out);     /* spp 5, max_bounces 20, BVH, all rows, no flags     */
+/* The header a host was compiled against and the library it loaded must agree: RT_ABI_VERSION changes whenever a
+ * struct of this header changes size or layout or an entry point changes meaning; rt_abi_version() is the value the
+ * library was built with, rt_stats_size() its sizeof(RtStats) (the struct that grows most often: rt_get_stats writes
+ * that many bytes).  No counterpart in the reference. */
+#define RT_ABI_VERSION 2
 int  rt_abi_version(void);
+size_t rt_stats_size(void);
 
 /* ------------------------------------------------------------------ several GPUs of one node
  * The reference renders on one GPU; these entry points have no counterpart in it beyond the per-frame

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "lib", "libraytr
 REPO_ROOT = os.path.dirname(_HERE)
 ASSETS_DIR = os.path.join(REPO_ROOT, "assets") + os.sep
 
+RT_ABI_VERSION = 2  # include/rt_abi.h
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT = -1
 RT_ERR_HIP = -2
@@ -110,7 +111,7 @@ class RtStats(C.Structure):
                 ("total_prims", C.c_int32), ("pipeline", C.c_int32),
                 ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64),
                 ("bvh_width", C.c_int32), ("frames", C.c_int32),
-                ("search_queue_peak", C.c_int32), ("search_queue_size", C.c_int32)]
+                ("search_queue_peak", C.c_int32), ("search_queue_size", C.c_int32), ("stack_overflow_steps", C.c_uint64)]
 
 
 class RtSceneView(C.Structure):
@@ -181,6 +182,7 @@ PROTOTYPES = {
     "rt_last_error": (C.c_char_p, [_P]),
     "rt_default_params": (None, [C.POINTER(RtParams)]),
     "rt_abi_version": (C.c_int, []),
+    "rt_stats_size": (C.c_size_t, []),
     "rt_scene_create": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(_P)]),
     "rt_scene_destroy": (C.c_int, [_P]),
     "rt_scene_add_material": (C.c_int, [_P, C.POINTER(RtMaterial)]),

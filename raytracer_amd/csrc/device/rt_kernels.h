@@ -52,7 +52,8 @@ struct FrameArgs {
     // per frame): [10..15] wave cycles in refill+raygen / search / shading, [16..17] per-lane traversal
     // iterations, [18..19] per-wave traversal iterations, [20..29] wave cycles of the five parts of
     // the continuation (pooled pipeline: [20..27] items << 32 | jobs per shading queue, [28..29] deep
-    // stack pushes, [32..39] wave cycles per shading queue)
+    // stack pushes, [32..39] wave cycles per shading queue, [40..43] lanes holding a ray / cycles inside the bursts,
+    // [44] the search queue's peak, [45] its size, [46..47] node visits that pushed into the device-memory stack overflow)
     uint32_t* counters;
     // Set to 1 (never cleared by a kernel) when the pooled kernel gave up waiting inside a workgroup and the
     // frame is incomplete; host-visible memory, so that the host sees it after a plain stream synchronise.

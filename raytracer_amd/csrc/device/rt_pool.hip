@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     unsigned long long wave_iters = 0, busy_iters = 0;  // STATS: search steps of this wave; lanes that had a ray at those steps
     uint32_t search_peak = 0;  // STATS: the most rays this wave saw waiting in the search queue
     unsigned long long deep_pushes = 0;  // STATS: pushes onto a stack already holding >= 4 (<< 32), >= 6 (<< 16), >= 8 entries
+    uint32_t overflow_steps = 0;         // STATS: node visits that left entries in the lane's overflow area in device memory
     unsigned long long job_stats[4] = {0, 0, 0, 0};  // STATS: per shading queue, items << 32 | jobs
     unsigned long long job_cycles[4] = {0, 0, 0, 0}, search_cycles = 0, step_cycles = 0;  // STATS: wave cycles (step_cycles: the part of search_cycles inside the burst of steps)
     const unsigned long long t_begin = STATS ? __builtin_readcyclecounter() : 0ull;
@@ -580,6 +581,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                         if (ACCEL == 2) trav_wide_step(sc.nodes, sl, stack, tv);
                         else trav_node_step(sc.nodes, sl, stack, tv);
                         if (STATS) n_nodes++;
+                        if (STATS && tv.sp > sp_before && tv.sp > kShortStack) overflow_steps++;
                         if (STATS && tv.sp > sp_before) deep_pushes += (sp_before >= 4 ? (1ull << 32) : 0ull) + (sp_before >= 8 ? 1ull : 0ull) + (sp_before >= 6 ? (1ull << 16) : 0ull);
                     }
                 } else {
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
     }
 
     // ---- counters: one atomic per wave
-    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests, nl = n_leaf_steps;
+    unsigned long long r = n_rays, nn = n_nodes, nt = n_tests, nl = n_leaf_steps, ov = overflow_steps;
     unsigned long long dp4 = deep_pushes >> 32, dp6 = (deep_pushes >> 16) & 0xffffu, dp8 = deep_pushes & 0xffffu;
     for (int off = 32; off > 0; off >>= 1) {
         if (STATS) { dp4 += __shfl_down(dp4, off); dp6 += __shfl_down(dp6, off); dp8 += __shfl_down(dp8, off); }
@@ -604,6 +606,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             nn += __shfl_down(nn, off);
             nt += __shfl_down(nt, off);
             nl += __shfl_down(nl, off);
+            ov += __shfl_down(ov, off);
         }
     }
     if (lane == 0) {
@@ -621,6 +624,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             atomicAdd((unsigned long long*)(fa.counters + 10), __builtin_readcyclecounter() - t_begin - shade_cycles - search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 12), search_cycles);
             atomicAdd((unsigned long long*)(fa.counters + 42), step_cycles);
+            atomicAdd((unsigned long long*)(fa.counters + 46), ov);
             atomicMax(fa.counters + 44, search_peak);
             fa.counters[45] = (uint32_t)kSearchRing;
             atomicAdd((unsigned long long*)(fa.counters + 14), shade_cycles);

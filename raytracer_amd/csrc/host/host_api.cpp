@@ -7,28 +7,17 @@
 
 #include "../../../include/rt_abi.h"
 #include "bvh_builder.h"
+#include "guarded.h"
 #include "scene_handle.h"
 
 using rt::Scene;
 
-// Nothing may throw across the C boundary: allocation failures (and whatever else a builder
-// might raise on hostile input) become status codes.
-template <typename F>
-static int guarded(F&& body) {
-    try {
-        return body();
-    } catch (const std::bad_alloc&) {
-        return RT_ERR_TOO_LARGE;
-    } catch (const std::length_error&) {
-        return RT_ERR_TOO_LARGE;
-    } catch (...) {
-        return RT_ERR_IO;
-    }
-}
+using rt::guarded;
 
 extern "C" {
 
-int rt_abi_version(void) { return 1; }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+size_t rt_stats_size(void) { return sizeof(RtStats); }
 
 void rt_default_params(RtParams* out) {
     if (!out) return;

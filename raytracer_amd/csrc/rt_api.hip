@@ -850,6 +850,7 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     memcpy(&out->cycles_steps, &h[42], 8);
     out->search_queue_peak = (int32_t)h[44];
     out->search_queue_size = (int32_t)h[45];
+    memcpy(&out->stack_overflow_steps, &h[46], 8);
     if (c->timed) RT_HIP(c, hipEventElapsedTime(&out->kernel_ms, c->ev_begin, c->ev_end));
     out->bvh_nodes = c->bvh_nodes;
     out->bvh_depth = c->bvh_depth;

@@ -93,3 +93,27 @@ def bit_equal_pixels(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     ub = np.ascontiguousarray(b).view(np.uint32)
     eq = ua == ub
     return eq.all(axis=-1) if eq.ndim == 3 else eq
+
+
+def assert_identical(g, o):
+    """Every output bit for bit: counts, sample-0 primary ids, per-pixel hash of all nearest-hit ids, accumulated
+    floats, BGRA8 bytes, ray count."""
+    assert np.array_equal(g["counts"], o["counts"])
+    assert np.array_equal(g["primary_ids"], o["primary_ids"])
+    assert np.array_equal(g["path_hash"], o["path_hash"])
+    assert bit_equal_pixels(g["accum"], o["accum"]).all()
+    assert np.array_equal(g["bgra"], o["bgra"])
+    assert g["total_rays"] == o["total_rays"]
+
+
+def assert_identical_but_edge_ties(g, o, max_share=1e-4):
+    """The same, except on edge-tie pixels (grazing hits whose Moeller-Trumbore result lies outside the padded leaf
+    box, which a tree search never tests): at most `max_share` of the image (one pixel at least).  Returns their
+    number."""
+    same = bit_equal_pixels(g["accum"], o["accum"]) & (g["path_hash"] == o["path_hash"])
+    bad = int((~same).sum())
+    assert bad <= max(1, int(max_share * same.size)), f"{bad} of {same.size} pixels differ"
+    assert np.array_equal(g["counts"], o["counts"])
+    assert np.array_equal(g["primary_ids"][same], o["primary_ids"][same])
+    assert np.array_equal(g["bgra"][same], o["bgra"][same])
+    return bad

@@ -41,7 +41,8 @@ def test_defaults_and_errors_without_gpu():
     p = capi.RtParams()
     lib.rt_default_params(C.byref(p))
     assert (p.spp, p.max_bounces, p.accel) == (5, 20, capi.RT_ACCEL_BVH)  # raytracer.comp:117-118
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == capi.RT_ABI_VERSION
+    assert lib.rt_stats_size() == C.sizeof(capi.RtStats)
     assert lib.rt_render_frame(None, None, None, None) == capi.RT_ERR_INVALID_ARGUMENT
     assert lib.rt_scene_create(99, None, C.byref(C.c_void_p())) == capi.RT_ERR_INVALID_ARGUMENT
 
@@ -63,3 +64,26 @@ def test_ctypes_structs_have_the_headers_sizes(tmp_path):
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
     for n in names:
         assert C.sizeof(getattr(capi, n)) == int(out[n]), f"{n}: ctypes {C.sizeof(getattr(capi, n))} bytes, header {out[n]}"
+
+
+def test_a_c_host_sees_the_librarys_abi_version_and_stats_size(tmp_path):
+    """A C host compiled against include/rt_abi.h and linked with the library: the header's RT_ABI_VERSION and its
+    sizeof(RtStats) must be what the library was built with (rt_get_stats writes rt_stats_size() bytes into the
+    caller's struct), and the ctypes mirror must carry the same version."""
+    import re
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "a C compiler is part of the build environment"
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "rt_abi.h"\nint main(void) {\n'
+                   '  printf("%d %d %zu %zu\\n", RT_ABI_VERSION, rt_abi_version(), sizeof(RtStats), rt_stats_size());\n'
+                   '  return (RT_ABI_VERSION == rt_abi_version() && sizeof(RtStats) == rt_stats_size()) ? 0 : 1;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run([cc, "-std=c99", "-I", os.path.dirname(HEADER), str(src), "-L", libdir, "-lraytracer_amd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    header_version = int(re.search(r"#define RT_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert header_version == capi.RT_ABI_VERSION == int(r.stdout.split()[0])

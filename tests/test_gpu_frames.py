@@ -94,3 +94,29 @@ def test_frames_that_cannot_be_fused_are_rendered_one_by_one(ctx):
         assert _same((acc, cnt, ctx.read_bgra8()), want)
     with pytest.raises(Exception):
         ctx.render_frames(default_camera(64, 64), [], params)
+
+
+def test_sixteen_fused_frames_against_the_oracle(ctx):
+    """The launch the benchmark times - sixteen frames of a still camera in one launch of the pooled kernel, library
+    defaults (four shading waves compiled in, four-wide tree, tile order fed back) - directly against the CPU
+    oracle's sixteen accumulated frames (flat loops, raytracer.comp:469-508), not only against frame-by-frame
+    rendering: accumulated floats, counts and BGRA8 bytes bit for bit but for edge-tie pixels (at most 1e-4 of the
+    image, one pixel at least), 144 image blocks so that every XCD owns several."""
+    from helpers import oracle_frames
+    scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
+    W, H, n = 128, 72, 16
+    o = oracle_frames(scene, W, H, spp=1, max_bounces=4, frames=n, threads=16)
+    cam = default_camera(W, H)
+    pcs = [scene.push_constants(0.0, k, k == 0) for k in range(n)]
+    for _ in range(2):  # the second launch runs on the tile order the first one measured
+        ctx.resize(W, H)
+        ctx.render_frames(cam, pcs, make_params(1, 4, capi.RT_ACCEL_BVH))
+        st = ctx.stats()
+        assert st.frames == n and st.pipeline == capi.RT_PIPELINE_POOLED and st.bvh_width == 4
+        acc, cnt = ctx.read_accum()
+        same = bit_equal_pixels(acc, o["accum"])
+        assert (~same).sum() <= 1, f"{(~same).sum()} pixels differ from the oracle"
+        assert (cnt == n).all() and np.array_equal(cnt, o["counts"])
+        assert np.array_equal(ctx.read_bgra8()[same], o["bgra"][same])
+        if same.all():
+            assert st.rays == o["total_rays"]

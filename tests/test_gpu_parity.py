@@ -11,7 +11,8 @@ Moeller-Trumbore result lies outside the padded leaf box); their share must stay
 import numpy as np
 import pytest
 
-from helpers import DEBUG_FLAGS, bit_equal_pixels, gpu_frames, oracle_frames
+from helpers import (DEBUG_FLAGS, assert_identical, assert_identical_but_edge_ties, bit_equal_pixels, gpu_frames,
+                     oracle_frames)
 from raytracer_amd import capi
 from raytracer_amd.renderer import Context, Controller, Scene, default_camera, look_camera, make_params
 
@@ -33,25 +34,6 @@ def star():
 @pytest.fixture(scope="module")
 def teapot():
     return Scene(capi.RT_SCENE_CORNELL_TEAPOT)
-
-
-def assert_identical(g, o):
-    assert np.array_equal(g["counts"], o["counts"])
-    assert np.array_equal(g["primary_ids"], o["primary_ids"])
-    assert np.array_equal(g["path_hash"], o["path_hash"])
-    assert bit_equal_pixels(g["accum"], o["accum"]).all()
-    assert np.array_equal(g["bgra"], o["bgra"])
-    assert g["total_rays"] == o["total_rays"]
-
-
-def assert_identical_but_edge_ties(g, o, max_share=1e-4):
-    same = bit_equal_pixels(g["accum"], o["accum"]) & (g["path_hash"] == o["path_hash"])
-    bad = int((~same).sum())
-    assert bad <= max(1, int(max_share * same.size)), f"{bad} of {same.size} pixels differ"
-    assert np.array_equal(g["counts"], o["counts"])
-    assert np.array_equal(g["primary_ids"][same], o["primary_ids"][same])
-    assert np.array_equal(g["bgra"][same], o["bgra"][same])
-    return bad
 
 
 def test_flat_star_bit_exact(ctx, star):
