@@ -82,7 +82,7 @@ def test_teapot_grid_against_the_oracle(ctx, grid, grid_oracle, pipeline, width)
     assert g["stats"].bvh_width == width
     assert g["stats"].pipeline == (capi.RT_PIPELINE_POOLED if pipeline == capi.RT_FLAG_POOLED else capi.RT_PIPELINE_SINGLE)
     assert_identical_but_edge_ties(g, grid_oracle)
-    assert (grid_oracle["primary_ids"] >= 8).mean() > 0.5  # most pixels see teapots (ids 0-3 are floor and lamp)
+    assert (grid_oracle["primary_ids"] >= 4).mean() > 0.3  # a good part of the frame sees teapots (ids 0-3 are floor and lamp)
 
 
 def test_teapot_grid_flat_search_equals_the_oracle_bit_for_bit(ctx, grid, grid_oracle):
