@@ -299,7 +299,7 @@ enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once t
        RT_OPT_TILE_CLASSES = 5,   /* cost classes of the frame-to-frame tile order (1..64, 16)                               */
        RT_OPT_POOL_PER_CU = 6,    /* pooled kernel: cap on workgroups per CU (0 = what fits, ..8)                            */
        RT_OPT_BVH_MAX_LEAF = 7,   /* most primitives per BVH leaf (1..8, 4)                                                  */
-       RT_OPT_POOL_SLOTS = 8,     /* pooled kernel: paths in flight per workgroup (0 = chosen by scene size, ..1344)         */
+       RT_OPT_POOL_SLOTS = 8,     /* pooled kernel: paths in flight per workgroup (0 = chosen by scene size, ..1344 = all)   */
        RT_OPT_BVH_TREELET = 9,    /* BVH node layout: levels per treelet (0 / 1 = depth-first order, ..16); next upload      */
        RT_OPT_BVH_WIDTH = 10,     /* pooled kernel: children per node of the tree it walks (2, 4; 0 = 4 when its stack fits) */
        RT_OPT_POOL_SHADER_WAVES = 11 }; /* pooled kernel: waves of a workgroup's 16 that only shade (1..8; 9 = none; 0 = by scene) */

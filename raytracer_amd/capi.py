@@ -235,9 +235,13 @@ def load() -> C.CDLL:
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            if older_build:
-                continue
-            raise
+            if not older_build:
+                raise
+            # say which entry point the other build lacks when it is called, not an AttributeError from ctypes
+            def missing(*_args, _name=name):
+                raise RuntimeError(f"{LIB_PATH} (RT_LIB_PATH) does not export {_name}: it was built from an older revision")
+            setattr(lib, name, missing)
+            continue
         fn.restype = res
         fn.argtypes = args
     _lib = lib

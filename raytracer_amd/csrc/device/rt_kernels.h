@@ -114,8 +114,9 @@ int pool_overflow_per_lane();  // the least a lane's overflow area holds; a four
 int pool_overflow_for(int stack_need);  // words per lane for a tree whose traversal holds up to stack_need entries
 int pool_threads_per_block();
 // accel: 0 the flat loops, 1 the binary tree, 2 the four-wide tree (sc.nodes must then be the wide nodes)
-// per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid)
-hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid);
+// per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid); accel / stats / batch / shader_waves name
+// the kernel instance launch_pool will pick (batch: a launch of several frames), whose occupancy is asked for
+hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, bool batch, int shader_waves, int cu_count, int per_cu_cap, unsigned* grid);
 hipError_t launch_pool(const DeviceScene& sc, const FrameArgs& fa, const PathPool& pp, int accel, bool stats, unsigned grid,
                        int refill_min, int burst, int job_min, int slots_cap, int shader_waves, hipStream_t stream);
 // How many XCDs a grid of one workgroup per CU is spread over (the hardware's XCC_ID of every workgroup, read

@@ -661,9 +661,9 @@ int pool_overflow_for(int stack_need) { return stack_need + 1 - kShortStack > kO
 // Workgroups of the pooled launch: as many as are resident at once, fewer when the image
 // is small.  The path pool must hold grid * pool_slots_per_block() cold records and
 // grid * pool_threads_per_block() * pool_overflow_per_lane() stack words.
-hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, int cu_count, int per_cu_cap, unsigned* grid) {
+hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, bool batch, int shader_waves, int cu_count, int per_cu_cap, unsigned* grid) {
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(accel, stats), kThreads, kStackLds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pick_kernel(accel, stats, batch, shader_waves), kThreads, kStackLds);
     if (e != hipSuccess) return e;
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     if (per_cu_cap >= 1 && per_cu_cap < per_cu) per_cu = per_cu_cap;

@@ -183,15 +183,20 @@ int rt_push_constants(RtPushConstants* out, const RtScene* s, float time, uint32
     return RT_OK;
 }
 
-int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost) {
-    if (!s) return RT_ERR_INVALID_ARGUMENT;
-    const Scene& sc = s->scene;
+static rt::SceneArrays arrays_of(const Scene& sc) {
     rt::SceneArrays a;
     a.spheres = sc.sphereVec.data();     a.n_spheres = sc.total_spheres;
     a.triangles = sc.triangleVec.data(); a.n_triangles = sc.total_triangles;
     a.vertices = sc.vertexVec.data();    a.n_vertices = (int32_t)sc.vertexVec.size();
     a.indices = sc.indexVec.data();      a.n_indices = (int32_t)sc.indexVec.size();
     a.meshes = sc.meshVec.data();        a.n_meshes = sc.total_meshes;
+    return a;
+}
+
+int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* n_prims, float* sah_cost) {
+    if (!s) return RT_ERR_INVALID_ARGUMENT;
+    return guarded([&]() -> int {
+    const rt::SceneArrays a = arrays_of(s->scene);
     rt::HostBvh bvh;
     std::string err;
     if (!rt::build_bvh(a, bvh, &err)) return RT_ERR_INVALID_ARGUMENT;
@@ -201,18 +206,14 @@ int rt_scene_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_
     if (n_prims) *n_prims = (int32_t)bvh.prim_order.size();
     if (sah_cost) *sah_cost = bvh.sah_cost;
     return RT_OK;
+    });
 }
 
 // The four-wide form of the scene's tree (what the pooled kernel walks on large scenes), built and checked.
 int rt_scene_wide_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, int32_t* stack_need) {
     if (!s) return RT_ERR_INVALID_ARGUMENT;
-    const Scene& sc = s->scene;
-    rt::SceneArrays a;
-    a.spheres = sc.sphereVec.data();     a.n_spheres = sc.total_spheres;
-    a.triangles = sc.triangleVec.data(); a.n_triangles = sc.total_triangles;
-    a.vertices = sc.vertexVec.data();    a.n_vertices = (int32_t)sc.vertexVec.size();
-    a.indices = sc.indexVec.data();      a.n_indices = (int32_t)sc.indexVec.size();
-    a.meshes = sc.meshVec.data();        a.n_meshes = sc.total_meshes;
+    return guarded([&]() -> int {
+    const rt::SceneArrays a = arrays_of(s->scene);
     rt::HostBvh bvh;
     rt::HostWideBvh wide;
     std::string err;
@@ -223,18 +224,14 @@ int rt_scene_wide_bvh_info(const RtScene* s, int32_t* n_nodes, int32_t* depth, i
     if (depth) *depth = wide.depth;
     if (stack_need) *stack_need = wide.stack_need;
     return RT_OK;
+    });
 }
 
 // FNV-1a over the BVH's node array and leaf order (what rt_upload_scene would copy to the device).
 int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash) {
     if (!s || !hash) return RT_ERR_INVALID_ARGUMENT;
-    const Scene& sc = s->scene;
-    rt::SceneArrays a;
-    a.spheres = sc.sphereVec.data();     a.n_spheres = sc.total_spheres;
-    a.triangles = sc.triangleVec.data(); a.n_triangles = sc.total_triangles;
-    a.vertices = sc.vertexVec.data();    a.n_vertices = (int32_t)sc.vertexVec.size();
-    a.indices = sc.indexVec.data();      a.n_indices = (int32_t)sc.indexVec.size();
-    a.meshes = sc.meshVec.data();        a.n_meshes = sc.total_meshes;
+    return guarded([&]() -> int {
+    const rt::SceneArrays a = arrays_of(s->scene);
     rt::HostBvh bvh;
     std::string err;
     if (!rt::build_bvh(a, bvh, &err)) return RT_ERR_INVALID_ARGUMENT;
@@ -247,6 +244,7 @@ int rt_scene_bvh_hash(const RtScene* s, uint64_t* hash) {
     mix(bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
     *hash = h;
     return RT_OK;
+    });
 }
 
 }  // extern "C"

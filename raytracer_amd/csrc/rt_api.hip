@@ -14,6 +14,7 @@
 #include "../../include/rt_abi.h"
 #include "device/rt_kernels.h"
 #include "host/bvh_builder.h"
+#include "host/guarded.h"
 #include "host/scene_handle.h"
 #include "rt_context.h"
 
@@ -47,7 +48,7 @@ namespace {
 constexpr size_t kScratchTiles = 128u * 1024u;      // 8x8 tiles of the largest frame (8.39 M pixels, e.g. 3840 x 2184)
 constexpr size_t kScratchStampBytes = 256;          // 8 words: what the stored tile order was made for
 constexpr size_t kScratchAuxBytes = 192u << 10;     // work area of the tile order kernels (rtd::tile_order_aux_bytes() <= this)
-constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (up to 1392 x 64 B records + 1024 x 24 stack words), rounded up
+constexpr size_t kScratchPoolBytes = 46u << 20;     // 256 pooled workgroups x (1344 x 64 B records + 1024 x 24 stack words) = 45.0 MiB, rounded up (the size dates from a pool of 1392 slots)
 constexpr size_t kScratchBytes = kScratchStampBytes + kScratchAuxBytes + 2 * 4 * kScratchTiles + kScratchPoolBytes;  // 47 MiB + 192 KiB + 256 B
 constexpr int kMaxDevices = 64;
 }  // namespace
@@ -144,6 +145,100 @@ int alloc_debug_buffers(RtContext* c) {
 
 }  // namespace
 
+namespace rtapi {
+
+// Everything rt_upload_scene checks and builds on the host: validated indices, the flat-order records, the binary
+// tree in its device form, its four-wide collapse.  materials / lights / triangles stay borrowed from the caller.
+int build_scene(const RtOptions& opt, const RtSphere* spheres, int32_t n_spheres, const RtMaterial* materials, int32_t n_materials,
+                const RtLight* lights, int32_t n_lights, const RtTriangle* triangles, int32_t n_triangles, const RtVertex* vertices,
+                int32_t n_vertices, const uint32_t* indices, int32_t n_indices, const RtMeshInfo* meshes, int32_t n_meshes, BuiltScene& out,
+                std::string& err) {
+    if (n_spheres < 0 || n_materials < 0 || n_lights < 0 || n_triangles < 0 || n_vertices < 0 || n_indices < 0 || n_meshes < 0) {
+        err = "negative element count";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if ((n_spheres && !spheres) || (n_materials && !materials) || (n_lights && !lights) || (n_triangles && !triangles) ||
+        (n_vertices && !vertices) || (n_indices && !indices) || (n_meshes && !meshes)) {
+        err = "null array with non-zero count";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    // The kernels index materials / triangles / vertices with values taken from the scene:
+    // check every such index on the host so that no launch can read out of bounds.
+    for (int32_t i = 0; i < n_spheres; ++i)
+        if (spheres[i].mat < 0 || spheres[i].mat >= n_materials) { err = "sphere material index out of range"; return RT_ERR_INVALID_ARGUMENT; }
+    for (int32_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].mat < 0 || triangles[i].mat >= n_materials) { err = "triangle material index out of range"; return RT_ERR_INVALID_ARGUMENT; }
+    for (int32_t i = 0; i < n_meshes; ++i)
+        if (meshes[i].material < 0 || meshes[i].material >= n_materials) { err = "mesh material index out of range"; return RT_ERR_INVALID_ARGUMENT; }
+    for (int32_t i = 0; i < n_lights; ++i) {
+        if (lights[i].type == RT_LIGHT_TRIANGLE) {
+            float fx = lights[i].pos_angle_aux[0];
+            if (!(fx >= 0.0f) || !(fx < (float)(n_triangles > 0 ? n_triangles : 1))) {
+                err = "TRIANGLE light refers to a triangle that does not exist";
+                return RT_ERR_INVALID_ARGUMENT;
+            }
+        }
+    }
+    rt::SceneArrays a;
+    a.spheres = spheres;     a.n_spheres = n_spheres;
+    a.triangles = triangles; a.n_triangles = n_triangles;
+    a.vertices = vertices;   a.n_vertices = n_vertices;
+    a.indices = indices;     a.n_indices = n_indices;
+    a.meshes = meshes;       a.n_meshes = n_meshes;
+    if (!rt::gather_primitives(a, out.flat, &err)) return RT_ERR_INVALID_ARGUMENT;
+    if (out.flat.size() >= (size_t)(1u << 28)) { err = "more than 2^28 primitives"; return RT_ERR_TOO_LARGE; }
+    if (!rt::build_bvh(a, out.bvh, &err, opt.bvh_max_leaf)) return RT_ERR_INVALID_ARGUMENT;
+    if (out.bvh.depth > rt::kMaxBvhDepth || out.bvh.max_leaf > 8) { err = "BVH exceeds traversal limits"; return RT_ERR_TOO_LARGE; }
+    rt::layout_treelets(out.bvh, opt.bvh_treelet);
+    // device form of a node: each child as the traversal's cursor word (an internal node's index, or
+    // bit 31 | (count - 1) << 28 | first record for a leaf), the count of an unused slot -1
+    out.dev_nodes = out.bvh.nodes;
+    for (rt::BvhNode& n : out.dev_nodes) {
+        if (n.child0 < 0) n.count0 = -1; else if (n.count0 > 0) n.child0 = (int32_t)(0x80000000u | ((uint32_t)(n.count0 - 1) << 28) | (uint32_t)n.child0);
+        if (n.child1 < 0) n.count1 = -1; else if (n.count1 > 0) n.child1 = (int32_t)(0x80000000u | ((uint32_t)(n.count1 - 1) << 28) | (uint32_t)n.child1);
+    }
+    rt::collapse_wide(out.bvh, out.wide);
+    out.materials = materials; out.n_materials = n_materials;
+    out.lights = lights;       out.n_lights = n_lights;
+    out.triangles = triangles; out.n_triangles = n_triangles;
+    out.n_spheres = n_spheres;
+    out.n_meshes = n_meshes;
+    return RT_OK;
+}
+
+// The device half of rt_upload_scene: copies of a built scene's arrays in this context's device memory.
+int upload_built(RtContext* c, const BuiltScene& b) {
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    int rc;
+    // (a failed upload still waits for the copies already queued: they read the host vectors)
+    auto bail = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+    if ((rc = upload_array(c, &c->d_prims_bvh, b.bvh.prims.data(), b.bvh.prims.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_prims_flat, b.flat.data(), b.flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_nodes, b.dev_nodes.data(), b.dev_nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_nodes_wide, b.wide.nodes.data(), b.wide.nodes.size() * sizeof(rt::WideNode), 128)) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_materials, b.materials, (size_t)b.n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_lights, b.lights, (size_t)b.n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return bail(rc);
+    if ((rc = upload_array(c, &c->d_triangles, b.triangles, (size_t)b.n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return bail(rc);
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // the caller's vectors may go out of scope
+    c->n_prims = (int32_t)b.flat.size();
+    c->n_spheres = b.n_spheres;
+    c->n_triangles = b.n_triangles;
+    c->n_meshes = b.n_meshes;
+    c->n_lights = b.n_lights;
+    c->n_materials = b.n_materials;
+    c->bvh_nodes = (int32_t)b.bvh.nodes.size();
+    c->bvh_depth = b.bvh.depth;
+    c->wide_nodes = (int32_t)b.wide.nodes.size();
+    c->wide_stack_need = b.wide.stack_need;
+    c->has_scene = true;
+    c->scene_generation++;
+    return RT_OK;
+}
+
+}  // namespace rtapi
+
 extern "C" {
 
 int rt_create(int device_ordinal, RtContext** out_ctx) {
@@ -233,77 +328,14 @@ int rt_upload_scene(RtContext* c, const RtSphere* spheres, int32_t n_spheres, co
                     int32_t n_triangles, const RtVertex* vertices, int32_t n_vertices, const uint32_t* indices,
                     int32_t n_indices, const RtMeshInfo* meshes, int32_t n_meshes) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
-    if (n_spheres < 0 || n_materials < 0 || n_lights < 0 || n_triangles < 0 || n_vertices < 0 || n_indices < 0 || n_meshes < 0)
-        return fail(c, RT_ERR_INVALID_ARGUMENT, "negative element count");
-    if ((n_spheres && !spheres) || (n_materials && !materials) || (n_lights && !lights) || (n_triangles && !triangles) ||
-        (n_vertices && !vertices) || (n_indices && !indices) || (n_meshes && !meshes))
-        return fail(c, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
-    // The kernels index materials / triangles / vertices with values taken from the scene:
-    // check every such index on the host so that no launch can read out of bounds.
-    for (int32_t i = 0; i < n_spheres; ++i)
-        if (spheres[i].mat < 0 || spheres[i].mat >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "sphere material index out of range");
-    for (int32_t i = 0; i < n_triangles; ++i)
-        if (triangles[i].mat < 0 || triangles[i].mat >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "triangle material index out of range");
-    for (int32_t i = 0; i < n_meshes; ++i)
-        if (meshes[i].material < 0 || meshes[i].material >= n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh material index out of range");
-    for (int32_t i = 0; i < n_lights; ++i) {
-        if (lights[i].type == RT_LIGHT_TRIANGLE) {
-            float fx = lights[i].pos_angle_aux[0];
-            if (!(fx >= 0.0f) || !(fx < (float)(n_triangles > 0 ? n_triangles : 1)))
-                return fail(c, RT_ERR_INVALID_ARGUMENT, "TRIANGLE light refers to a triangle that does not exist");
-        }
-    }
-    rt::SceneArrays a;
-    a.spheres = spheres;     a.n_spheres = n_spheres;
-    a.triangles = triangles; a.n_triangles = n_triangles;
-    a.vertices = vertices;   a.n_vertices = n_vertices;
-    a.indices = indices;     a.n_indices = n_indices;
-    a.meshes = meshes;       a.n_meshes = n_meshes;
-    std::vector<rt::PrimRecord> flat;
-    std::string err;
-    if (!rt::gather_primitives(a, flat, &err)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
-    if (flat.size() >= (size_t)(1u << 28)) return fail(c, RT_ERR_TOO_LARGE, "more than 2^28 primitives");
-    rt::HostBvh bvh;
-    if (!rt::build_bvh(a, bvh, &err, c->opt.bvh_max_leaf)) return fail(c, RT_ERR_INVALID_ARGUMENT, err);
-    if (bvh.depth > rt::kMaxBvhDepth || bvh.max_leaf > 8) return fail(c, RT_ERR_TOO_LARGE, "BVH exceeds traversal limits");
-    rt::layout_treelets(bvh, c->opt.bvh_treelet);
-
-    RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
-    free_scene(c);
-    int rc;
-    // (a failed upload still waits for the copies already queued: they read the host vectors below)
-    auto bail = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
-    if ((rc = upload_array(c, &c->d_prims_bvh, bvh.prims.data(), bvh.prims.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
-    if ((rc = upload_array(c, &c->d_prims_flat, flat.data(), flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
-    // device form of a node: each child as the traversal's cursor word (an internal node's index, or
-    // bit 31 | (count - 1) << 28 | first record for a leaf), the count of an unused slot -1
-    std::vector<rt::BvhNode> dev_nodes(bvh.nodes);
-    for (rt::BvhNode& n : dev_nodes) {
-        if (n.child0 < 0) n.count0 = -1; else if (n.count0 > 0) n.child0 = (int32_t)(0x80000000u | ((uint32_t)(n.count0 - 1) << 28) | (uint32_t)n.child0);
-        if (n.child1 < 0) n.count1 = -1; else if (n.count1 > 0) n.child1 = (int32_t)(0x80000000u | ((uint32_t)(n.count1 - 1) << 28) | (uint32_t)n.child1);
-    }
-    if ((rc = upload_array(c, &c->d_nodes, dev_nodes.data(), dev_nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return bail(rc);
-    rt::HostWideBvh wide;
-    rt::collapse_wide(bvh, wide);
-    if ((rc = upload_array(c, &c->d_nodes_wide, wide.nodes.data(), wide.nodes.size() * sizeof(rt::WideNode), 128)) != RT_OK) return bail(rc);
-    if ((rc = upload_array(c, &c->d_materials, materials, (size_t)n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return bail(rc);
-    if ((rc = upload_array(c, &c->d_lights, lights, (size_t)n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return bail(rc);
-    if ((rc = upload_array(c, &c->d_triangles, triangles, (size_t)n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return bail(rc);
-    RT_HIP(c, hipStreamSynchronize(c->stream));  // host vectors above go out of scope
-    c->n_prims = (int32_t)flat.size();
-    c->n_spheres = n_spheres;
-    c->n_triangles = n_triangles;
-    c->n_meshes = n_meshes;
-    c->n_lights = n_lights;
-    c->n_materials = n_materials;
-    c->bvh_nodes = (int32_t)bvh.nodes.size();
-    c->bvh_depth = bvh.depth;
-    c->wide_nodes = (int32_t)wide.nodes.size();
-    c->wide_stack_need = wide.stack_need;
-    c->has_scene = true;
-    c->scene_generation++;
-    return RT_OK;
+    return rt::guarded([&]() -> int {
+        rtapi::BuiltScene built;
+        std::string err;
+        int rc = rtapi::build_scene(c->opt, spheres, n_spheres, materials, n_materials, lights, n_lights, triangles, n_triangles, vertices,
+                                    n_vertices, indices, n_indices, meshes, n_meshes, built, err);
+        if (rc != RT_OK) return fail(c, rc, err);
+        return rtapi::upload_built(c, built);
+    });
 }
 
 int rt_upload_scene_from(RtContext* c, const RtScene* s) {
@@ -440,7 +472,7 @@ static bool pooled_fits(const RtContext* c, const RtParams& p) {
 }
 
 // Paths in flight per pooled workgroup.  A single frame of a scene far beyond the L2 caches (the 84 MB of the
-// 1.07 M-triangle scene against 8 x 4 MB) runs faster with fewer (final kernel: 1392 slots 12.35 ms, 1152 11.9, 896 11.75):
+// 1.07 M-triangle scene against 8 x 4 MB) runs faster with fewer (measured while a pool held 1392 slots: 1392 slots 12.35 ms, 1152 11.9, 896 11.75):
 // its long rays make the last generation of paths expensive, and fewer slots make that generation smaller.  A launch
 // of several frames has one such generation for all of them and wants every slot (4 frames: 896 slots 10.84 ms per
 // frame, 1152 10.25, 1392 10.10), as do the scenes that fit the caches.
@@ -643,7 +675,8 @@ static int render_impl(RtContext* c, const RtCamera* camera, const RtPushConstan
     }
     unsigned grid = 0;
     if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
-        RT_HIP(c, rtd::pool_grid(fa, p.accel, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, c->cu_count, c->opt.pool_per_cu, &grid));
+        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, pooled_overflow_words(c)) == 4 ? 2 : 1) : 0, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0,
+                                 n_frames > 1, pool_shader_waves(c, n_frames), c->cu_count, c->opt.pool_per_cu, &grid));
         rc = ensure_pool_bytes(c, pooled_pool_bytes(grid, pooled_overflow_words(c)));
         if (rc != RT_OK) return rc;
     }
@@ -756,7 +789,8 @@ int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushCo
     }
     unsigned grid = 0;
     if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
-        RT_HIP(c, rtd::pool_grid(fa, p.accel, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, c->cu_count, c->opt.pool_per_cu, &grid));
+        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, rtd::pool_overflow_per_lane()) == 4 ? 2 : 1) : 0,
+                                 (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, false, pool_shader_waves(c, 1), c->cu_count, c->opt.pool_per_cu, &grid));
         const unsigned fits = (unsigned)(kScratchPoolBytes / pooled_pool_bytes(1, rtd::pool_overflow_per_lane()));
         grid = grid > fits ? fits : grid;  // fewer workgroups than CUs still render the whole frame
     }
@@ -774,7 +808,7 @@ int rt_set_option(RtContext* c, int option, int value) {
         {RT_OPT_EXIT_QUOTA_PCT, &c->opt.exit_quota_pct, 1, 100}, {RT_OPT_REFILL_MIN, &c->opt.refill_min, 1, 64},
         {RT_OPT_POOL_BURST, &c->opt.pool_burst, 0, 1024},        {RT_OPT_POOL_JOB_MIN, &c->opt.pool_job_min, 0, 64},
         {RT_OPT_TILE_CLASSES, &c->opt.tile_classes, 1, 64},      {RT_OPT_POOL_PER_CU, &c->opt.pool_per_cu, 0, 8},
-        {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8},       {RT_OPT_POOL_SLOTS, &c->opt.pool_slots, 0, 4096},
+        {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8},       {RT_OPT_POOL_SLOTS, &c->opt.pool_slots, 0, rtd::pool_slots_per_block()},
         {RT_OPT_BVH_TREELET, &c->opt.bvh_treelet, 0, 16},        {RT_OPT_BVH_WIDTH, &c->opt.bvh_width, 0, 4},
         {RT_OPT_POOL_SHADER_WAVES, &c->opt.pool_shader_waves, 0, 9}};
     for (const auto& t : table) {

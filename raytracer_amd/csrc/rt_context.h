@@ -5,8 +5,10 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/rt_abi.h"
+#include "host/bvh_builder.h"
 
 // Tuning knobs (rt_set_option; defaults may be overridden once, at rt_create, by the environment
 // variables named in rt_api.hip).
@@ -86,6 +88,23 @@ struct RtContext {
 };
 
 namespace rtapi {
+// A scene as rt_upload_scene prepares it on the host, ready to be copied to any number of devices (the tree build is
+// the expensive part: seconds for a million triangles).  materials / lights / triangles are borrowed from the caller.
+struct BuiltScene {
+    std::vector<rt::PrimRecord> flat;    // the reference's loop order
+    rt::HostBvh bvh;                     // binary tree; bvh.prims = the records in leaf order
+    std::vector<rt::BvhNode> dev_nodes;  // bvh.nodes with children as cursor words
+    rt::HostWideBvh wide;                // four-wide collapse of the same tree
+    const RtMaterial* materials = nullptr; int32_t n_materials = 0;
+    const RtLight* lights = nullptr;       int32_t n_lights = 0;
+    const RtTriangle* triangles = nullptr; int32_t n_triangles = 0;
+    int32_t n_spheres = 0, n_meshes = 0;
+};
+int build_scene(const RtOptions& opt, const RtSphere* spheres, int32_t n_spheres, const RtMaterial* materials, int32_t n_materials,
+                const RtLight* lights, int32_t n_lights, const RtTriangle* triangles, int32_t n_triangles, const RtVertex* vertices,
+                int32_t n_vertices, const uint32_t* indices, int32_t n_indices, const RtMeshInfo* meshes, int32_t n_meshes, BuiltScene& out,
+                std::string& err);
+int upload_built(RtContext* c, const BuiltScene& b);
 int fail(RtContext* ctx, int code, const std::string& msg);
 // after a stream synchronise: RT_ERR_HIP (once) if a pooled frame was abandoned since the last report
 int check_abandoned(RtContext* c);

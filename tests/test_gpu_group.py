@@ -119,3 +119,66 @@ def test_group_batch_of_frames_equals_frame_by_frame(mode):
         assert bit_equal_pixels(acc, want_acc).all() and np.array_equal(cnt, want_cnt) and (cnt == F).all()
     finally:
         g.close()
+
+
+def _one_context(scene, W, H, frame_counts, params):
+    ctx = Context(0)
+    try:
+        ctx.upload_scene(scene)
+        ctx.resize(W, H)
+        for k, f in enumerate(frame_counts):
+            ctx.render_frame(default_camera(W, H), scene.push_constants(0.0, f, k == 0), params)
+        acc, cnt = ctx.read_accum()
+        return acc.copy(), cnt.copy(), ctx.read_bgra8().copy()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_group_of_several_contexts_on_one_device(n):
+    """The n-device code of RtGroup - per-context strips, staging offsets, the skipped own share, the exchange stream
+    beside the next call's kernels, the deferred unpack, the samples' reduction - with n contexts on the one GPU a
+    test box has (contexts that share a device exchange through device copies instead of RCCL, which wants a GPU
+    per rank; everything else is the same code).  Strips: every context ends up with the whole frame, bit for bit
+    what one context renders; frame by frame and in a batch.  Samples: the sum over the contexts equals sequential
+    accumulation within 4e-7 x frames (the order of the float sums differs), counts exactly."""
+    scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
+    W, H, rows = 200, 117, 9
+    params = make_params(2, 4, capi.RT_ACCEL_BVH)
+    cam = default_camera(W, H)
+    want = _one_context(scene, W, H, range(5), params)
+    g = Group([0] * n)
+    try:
+        assert len(g) == n
+        g.upload_scene(scene)
+        g.resize(W, H)
+        # strips, one call per frame (each call's exchange runs beside the next call's kernels), then a batch on top
+        for f in range(3):
+            g.render_frame(cam, scene.push_constants(0.0, f, f == 0), params, capi.RT_GROUP_STRIPS, rows)
+        g.render_frames(cam, scene.push_constants(0.0, 3, False), params, capi.RT_GROUP_STRIPS, rows, 2)
+        g.sync()
+        for i in range(n):
+            c = g.context(i)
+            acc, cnt = c.read_accum()
+            assert bit_equal_pixels(acc, want[0]).all() and np.array_equal(cnt, want[1]) and (cnt == 5).all(), f"context {i} of {n}"
+            assert np.array_equal(c.read_bgra8(), want[2]), f"context {i} of {n}"
+        # another partition of the same frames on the same group: strips of 4 rows, a reset on the first frame
+        g.render_frames(cam, scene.push_constants(0.0, 0, True), params, capi.RT_GROUP_STRIPS, 4, 5)
+        g.sync()
+        acc, cnt = g.context(n - 1).read_accum()
+        assert bit_equal_pixels(acc, want[0]).all() and np.array_equal(cnt, want[1])
+        # samples: 2 n frames, context i renders frames i and i + n; the reduction lands on context 0
+        frames = 2 * n
+        seq = _one_context(scene, W, H, range(frames), params)
+        g.render_frames(cam, scene.push_constants(0.0, 0, True), params, capi.RT_GROUP_SAMPLES, 0, 2)
+        g.reduce_samples()
+        acc, cnt = g.read_total()
+        assert np.array_equal(cnt, seq[1]) and (cnt == frames).all()
+        assert np.abs(acc - seq[0]).max() <= 4e-7 * frames * max(1.0, float(np.abs(seq[0]).max()))
+        g.sync()
+        packed = np.abs(g.context(0).read_bgra8().astype(np.int32) - seq[2].astype(np.int32)).max()
+        assert packed <= 1  # the image of the sum: a rounding boundary may fall the other way
+        own, own_cnt = g.context(1).read_accum()  # the contexts' own accumulators are left as they are
+        assert (own_cnt == 2).all() and not bit_equal_pixels(own, acc).all()
+    finally:
+        g.close()
