@@ -95,6 +95,29 @@ struct PoolCtl {
     uint32_t count[kQueues], live, abort;
 };
 
+// The cold records are written once and read once, far apart in time: with RT_COLD_NT their accesses carry the
+// non-temporal hint (1: stores, 2: stores and loads), so that they do not displace the scene in the L2.
+#ifndef RT_COLD_NT
+#define RT_COLD_NT 0
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+RT_DEV float4 cold_load(const float4* p) {
+#if RT_COLD_NT >= 2
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+RT_DEV void cold_store(float4* p, float4 v) {
+#if RT_COLD_NT >= 1
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (f32x4*)p);
+#else
+    *p = v;
+#endif
+}
+
 // Accessor of slot i: hot fields in LDS, cold record (pixel sum, pixel cost | the light's term: normal,
 // light distance | incoming direction, packed bits | light direction, hit id; 64 bytes) in device memory.
 struct PoolSlot {
@@ -121,20 +144,20 @@ struct PoolSlot {
     RT_DEV KernargFloats camera(const FrameArgs&) const { return kernarg_camera(); }  // pool_kernel(DeviceScene, FrameArgs, ...)
     RT_DEV FrameArgs late_frame(const FrameArgs&) const { return kernarg_frame(); }
     RT_DEV uint32_t frame_count_of(uint32_t frame) const { return kernarg_frame_count(frame); }
-    RT_DEV V3 get_pix(float& cost) const { const float4 v = cold[0]; cost = v.w; return xyz(v); }
-    RT_DEV void put_pix(V3 v, float cost) const { cold[0] = f4(v, cost); }
+    RT_DEV V3 get_pix(float& cost) const { const float4 v = cold_load(cold + 0); cost = v.w; return xyz(v); }
+    RT_DEV void put_pix(V3 v, float cost) const { cold_store(cold + 0, f4(v, cost)); }
     RT_DEV void put_hash(uint32_t phash) const { L.phash[i] = phash; }
     // What the light's term of the sample needs at its end (LightRecord), 44 bytes of the cold record:
     // normal, light distance | incoming direction, front face << 31 | light << 16 | material | light
     // direction, the query's hit id (hash mode).  (The host offers this kernel only to scenes with at most
     // 32768 lights and 65536 materials.)
     RT_DEV void put_light_record(const LightRecord& q) const {
-        cold[1] = f4(q.normal, q.s_d);
-        cold[2] = f4(q.vdir, __uint_as_float((q.front_face ? 0x80000000u : 0u) | ((uint32_t)q.light << 16) | (uint32_t)q.mat));
-        cold[3] = f4(q.ldir, 0.0f);
+        cold_store(cold + 1, f4(q.normal, q.s_d));
+        cold_store(cold + 2, f4(q.vdir, __uint_as_float((q.front_face ? 0x80000000u : 0u) | ((uint32_t)q.light << 16) | (uint32_t)q.mat)));
+        cold_store(cold + 3, f4(q.ldir, 0.0f));
     }
     RT_DEV void get_light_record(LightRecord& q) const {
-        const float4 n = cold[1], v = cold[2], l = cold[3];
+        const float4 n = cold_load(cold + 1), v = cold_load(cold + 2), l = cold_load(cold + 3);
         const uint32_t bits = __float_as_uint(v.w);
         q.normal = xyz(n); q.s_d = n.w;
         q.vdir = xyz(v); q.light = (int)((bits >> 16) & 0x7fffu);

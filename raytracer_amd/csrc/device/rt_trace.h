@@ -123,8 +123,8 @@ RT_DEV void trav_pop(Trav& tv, const Stack& stack) {
 }
 
 // Constants of the slab test for one ray: t = box * inv + off per axis.  The arithmetic
-// runs on a direction with no zero component; the boxes are padded on the host by far more
-// than the half-ulp origin perturbation the fused form implies.  The box test only has to
+// runs on a direction with no zero component; the boxes are padded on the host by more
+// than the origin perturbation the fused form implies (host/bvh_builder.cpp).  The box test only has to
 // be conservative, so the hardware's approximate reciprocal (1 ulp) is enough here; the
 // exact arithmetic is kept for the primitive tests.
 struct Slab {
@@ -187,7 +187,8 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
 // cursor words, padding): slab-test the four children, descend into the nearest one hit, push the others,
 // farthest first.  With centre and half extent the entry and exit distances need no min / max per axis:
 // (c * inv + off) -+ h * |inv|.  An empty place has a negative half extent: its entry lies behind its exit.
-// The boxes are padded by 1e-4 of the scene's scale on the host, a thousand times the rounding of these sums.
+// The boxes are padded on the host by 5e-6 of the scene's scale, five times what the rounding of these sums and of the
+// reciprocal can amount to for rays that start inside the scene (host/bvh_builder.cpp).
 template <typename Stack>
 RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
     const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;

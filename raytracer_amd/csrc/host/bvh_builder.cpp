@@ -46,13 +46,23 @@ struct BuildPrim {
     int32_t flat_index;
 };
 
-// Boxes are padded so that a hit the intersection routine accepts a few ulps outside the
-// exact primitive (rounding in Moeller-Trumbore's u, v, t) still lies inside its leaf box.
-Box padded(const Box& b) {
+// Boxes are padded so that (a) a hit the intersection routine accepts a few ulps outside the exact primitive
+// (rounding in Moeller-Trumbore's u, v, t) still lies inside its leaf box and (b) the traversal's slab test, which
+// runs in fused arithmetic on a reciprocal good to 1 ulp, never culls a box the exact test would enter.  Both
+// errors grow with the magnitude of the ray's origin and the distance walked, not with the primitive's own
+// coordinates: in position units at most about 2.5e-7 x (|origin| + |box| + distance) <= 1e-6 x S for rays that
+// start inside a scene whose coordinates reach S.  The pad is the same for every primitive, kPadOfScale x max(1, S):
+// five times that bound (a camera further than about 4 S from the origin eats into the margin).  Until round 3 of
+// this build it was 1e-4 x max(1, the primitive's own largest coordinate): up to 2e-3 on the 0.03-wide triangles of
+// the 1.07 M-triangle scene, 3 % of whose node visits and 6 % of whose primitive tests were the pad's.  Measured
+// with the pad at 5e-8 of the primitive's coordinate: still no pixel differs from the flat search (tools/edge_ties.py).
+const float kPadOfScale = 5e-6f;
+float pad_of_scale(float scale) {
+    static const float k = getenv("RT_BVH_PAD") ? (float)atof(getenv("RT_BVH_PAD")) : kPadOfScale;  // the variable: tuning aid
+    return k * std::fmax(1.0f, scale);
+}
+Box padded(const Box& b, float pad) {
     Box r = b;
-    float m = 1.0f;
-    for (int k = 0; k < 3; ++k) m = std::fmax(m, std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
-    float pad = 1e-4f * m;
     for (int k = 0; k < 3; ++k) {
         r.lo[k] = b.lo[k] - pad;
         r.hi[k] = b.hi[k] + pad;
@@ -60,7 +70,7 @@ Box padded(const Box& b) {
     return r;
 }
 
-Box prim_box(const PrimRecord& p) {
+Box exact_box(const PrimRecord& p) {
     Box b;
     if (p.mat & kSphereFlag) {
         float r = std::fabs(p.b[0]);
@@ -75,7 +85,16 @@ Box prim_box(const PrimRecord& p) {
         b.grow(v1);
         b.grow(v2);
     }
-    return padded(b);
+    return b;
+}
+// Largest coordinate magnitude of the scene's primitives.
+float scene_scale(const std::vector<PrimRecord>& prims) {
+    float m = 0.0f;
+    for (const PrimRecord& p : prims) {
+        const Box b = exact_box(p);
+        for (int k = 0; k < 3; ++k) m = std::fmax(m, std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    }
+    return m;
 }
 
 struct ChildRef {
@@ -348,8 +367,9 @@ bool build_bvh(const SceneArrays& s, HostBvh& out, std::string* err, int max_lea
     std::vector<PrimRecord> flat;
     if (!gather_primitives(s, flat, err)) return false;
     std::vector<BuildPrim> bp(flat.size());
+    const float pad = pad_of_scale(scene_scale(flat));
     for (size_t i = 0; i < flat.size(); ++i) {
-        bp[i].box = prim_box(flat[i]);
+        bp[i].box = padded(exact_box(flat[i]), pad);
         for (int k = 0; k < 3; ++k) bp[i].centroid[k] = 0.5f * (bp[i].box.lo[k] + bp[i].box.hi[k]);
         bp[i].flat_index = (int32_t)i;
         for (int k = 0; k < 3; ++k)
@@ -611,6 +631,7 @@ bool validate_bvh(const HostBvh& bvh, std::string* err) {
             if (inner.lo[k] < outer.lo[k] || inner.hi[k] > outer.hi[k]) return false;
         return true;
     };
+    const float pad = pad_of_scale(scene_scale(bvh.prims));
     Item it[2];
     node_seen[0] = 1;
     child_items(bvh.nodes[0], 1, it);
@@ -628,7 +649,7 @@ bool validate_bvh(const HostBvh& bvh, std::string* err) {
                 return fail(err, "leaf range out of bounds");
             for (int k = 0; k < cur.count; ++k) {
                 if (prim_seen[cur.child + k]++) return fail(err, "primitive referenced by two leaves");
-                Box pb = prim_box(bvh.prims[cur.child + k]);
+                Box pb = padded(exact_box(bvh.prims[cur.child + k]), pad);
                 if (!inside(pb, cur.box)) return fail(err, "leaf box does not contain its primitive");
             }
         } else {
