@@ -541,3 +541,36 @@ def test_shading_waves_change_the_schedule_only(ctx, teapot):
     finally:
         ctx.set_option(capi.RT_OPT_POOL_SHADER_WAVES, 0)
         ctx.set_option(capi.RT_OPT_POOL_JOB_MIN, 0)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_benchmark_sampling_against_the_oracle(ctx, teapot, fused):
+    """The benchmark's scene, camera and sampling (C3: Cornell box + teapot.glb, 16 spp, 4 bounces, still camera, two
+    accumulated frames) at an eighth of its width and height, where the oracle's flat loops finish in seconds: the
+    library's own choice of kernel, frame by frame and as one fused launch, against the oracle - accumulated floats,
+    counts, BGRA8 bytes (and the ray count where no pixel is an edge tie)."""
+    from raytracer_amd.workloads import WORKLOADS
+    _, _, _, spp, mb, _ = WORKLOADS["c3"]
+    W, H, n = 240, 135, 2
+    o = oracle_frames(teapot, W, H, spp=spp, max_bounces=mb, frames=n, threads=16)
+    ctx.upload_scene(teapot)
+    ctx.resize(W, H)
+    cam = default_camera(W, H)
+    pcs = [teapot.push_constants(0.0, f, f == 0) for f in range(n)]
+    rays = 0
+    if fused:
+        ctx.render_frames(cam, pcs, make_params(spp, mb, capi.RT_ACCEL_BVH))
+        assert ctx.stats().frames == n
+        rays = ctx.stats().rays
+    else:
+        for pc in pcs:
+            ctx.render_frame(cam, pc, make_params(spp, mb, capi.RT_ACCEL_BVH))
+            rays += ctx.stats().rays
+    assert ctx.stats().pipeline == capi.RT_PIPELINE_POOLED and ctx.stats().bvh_width == 4
+    acc, cnt = ctx.read_accum()
+    same = bit_equal_pixels(acc, o["accum"])
+    assert (~same).sum() <= 3, f"{(~same).sum()} of {same.size} pixels differ from the oracle"
+    assert np.array_equal(cnt, o["counts"]) and (cnt == n).all()
+    assert np.array_equal(ctx.read_bgra8()[same], o["bgra"][same])
+    if same.all():
+        assert rays == o["total_rays"]

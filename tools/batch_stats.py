@@ -3,9 +3,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import capi
 from raytracer_amd.renderer import Context, Scene, make_params
 from raytracer_amd.workloads import WORKLOADS, workload_camera
-preset, FW, FH, spp, mb, _ = WORKLOADS["c3"]
-s = Scene(preset); cam = workload_camera("c3", FW, FH)
 F = int(sys.argv[1])
+wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
+preset, FW, FH, spp, mb, _ = WORKLOADS[wl]
+s = Scene(preset); cam = workload_camera(wl, FW, FH)
 ctx = Context(0); ctx.upload_scene(s); ctx.resize(FW, FH)
 for l in range(4):
     flags = capi.RT_FLAG_POOLED | (capi.RT_FLAG_TRAVERSAL_STATS if l == 3 else 0)
@@ -15,5 +16,5 @@ for l in range(4):
 st = ctx.stats()
 tot = max(1, st.cycles_raygen + st.cycles_search + st.cycles_shade)
 jc = list(st.pool_job_cycles); parts = list(st.cycles_shade_parts)
-print(f"F={F}: kernel {st.kernel_ms:.3f} ms = {st.kernel_ms/F:.3f} per frame, rays {st.rays}; search {st.cycles_search/tot:.3f} (steps {st.cycles_steps/tot:.3f}) other {st.cycles_raygen/tot:.3f} shading {st.cycles_shade/tot:.3f}: "
+print(f"{wl} F={F}: kernel {st.kernel_ms:.3f} ms = {st.kernel_ms/F:.3f} per frame, rays {st.rays}; search {st.cycles_search/tot:.3f} (steps {st.cycles_steps/tot:.3f}) other {st.cycles_raygen/tot:.3f} shading {st.cycles_shade/tot:.3f}: "
       + " ".join(f"{c/tot:.3f}" for c in jc) + f"; lanes with ray {st.busy_lane_iterations/(64*max(1,st.wave_iterations)):.3f}; jobs " + " ".join(str(v & 0xffffffff) for v in parts[:4]))
