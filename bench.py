@@ -365,8 +365,9 @@ def main() -> None:
             # (the pooled kernel's four-wide tree) -, 51 flop per triangle test; 48 B per tested primitive
             # record; + 48 B framebuffer per pixel
             width = st.bvh_width if st.bvh_width in (2, 4) else 2
+            node_bytes = st.bvh_node_bytes if st.bvh_node_bytes > 0 else 32 * width  # 64 binary, 128 or 80 (binary16 boxes) four-wide
             flops_per_ray = 24.0 * width * nodes_per_ray + 51.0 * tests_per_ray
-            bytes_per_ray = 32.0 * width * nodes_per_ray + 48.0 * tests_per_ray
+            bytes_per_ray = float(node_bytes) * nodes_per_ray + 48.0 * tests_per_ray
         else:
             flops_per_ray = 30.0 * v.total_spheres + 51.0 * (n_prims - v.total_spheres)
             bytes_per_ray = 48.0 * n_prims
@@ -439,6 +440,7 @@ def main() -> None:
                 "bytes_per_ray": bytes_per_ray,
                 "nodes_per_ray": nodes_per_ray,
                 "children_per_node": st.bvh_width,
+                "node_bytes": st.bvh_node_bytes,
                 "prim_tests_per_ray": tests_per_ray,
                 "algorithmic_GBps": launch_bytes / (avg_kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": PEAK_HBM_GBPS,

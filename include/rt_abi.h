@@ -191,6 +191,9 @@ typedef struct RtStats {
                                    for a lane at once ...                                                            */
     int32_t  search_queue_size; /* ... and what that queue holds (a ray pushed beyond it would be lost, and the frame
                                    would fail with RT_ERR_HIP instead of finishing)                                  */
+    int32_t  bvh_node_bytes; /* bytes per node of the tree the last frame's kernel walked: 64 (binary), 128 or 80 (four-wide,
+                                see RT_OPT_BVH_NODE_FORMAT); 0 for the flat loops                                     */
+    int32_t  reserved0;
     uint64_t stack_overflow_steps; /* pooled pipeline with TRAVERSAL_STATS: node visits that pushed onto a traversal stack
                                       whose part in LDS was already full, i.e. whose entries went to the lane's overflow
                                       area in device memory                                                          */
@@ -302,7 +305,10 @@ enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once t
        RT_OPT_POOL_SLOTS = 8,     /* pooled kernel: paths in flight per workgroup (0 = chosen by scene size, ..1344 = all)   */
        RT_OPT_BVH_TREELET = 9,    /* BVH node layout: levels per treelet (0 / 1 = depth-first order, ..16); next upload      */
        RT_OPT_BVH_WIDTH = 10,     /* pooled kernel: children per node of the tree it walks (2, 4; 0 = 4 when its stack fits) */
-       RT_OPT_POOL_SHADER_WAVES = 11 }; /* pooled kernel: waves of a workgroup's 16 that only shade (1..8; 9 = none; 0 = by scene) */
+       RT_OPT_POOL_SHADER_WAVES = 11, /* pooled kernel: waves of a workgroup's 16 that only shade (1..8; 9 = none; 0 = by scene) */
+       RT_OPT_BVH_NODE_FORMAT = 12 }; /* pooled kernel, four-wide tree: 32 = 128-byte nodes (binary32 boxes), 16 = 80-byte nodes
+                                       (binary16 boxes relative to a point of the node, rounded outwards: same results, fewer
+                                       bytes fetched per visit); 0 = 16 for scenes beyond 16 MB, else 32                     */
 int rt_set_option(RtContext* ctx, int option, int value);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);

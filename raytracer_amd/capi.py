@@ -44,6 +44,7 @@ RT_GROUP_STRIPS, RT_GROUP_SAMPLES = 0, 1
 RT_OPT_EXIT_QUOTA_PCT, RT_OPT_REFILL_MIN, RT_OPT_POOL_BURST, RT_OPT_POOL_JOB_MIN = 1, 2, 3, 4
 RT_OPT_TILE_CLASSES, RT_OPT_POOL_PER_CU, RT_OPT_BVH_MAX_LEAF, RT_OPT_POOL_SLOTS, RT_OPT_BVH_TREELET, RT_OPT_BVH_WIDTH = 5, 6, 7, 8, 9, 10
 RT_OPT_POOL_SHADER_WAVES = 11
+RT_OPT_BVH_NODE_FORMAT = 12
 
 RT_SCENE_EMPTY = 0
 RT_SCENE_CORNELL_STAR = 1
@@ -111,7 +112,8 @@ class RtStats(C.Structure):
                 ("total_prims", C.c_int32), ("pipeline", C.c_int32),
                 ("pool_job_cycles", C.c_uint64 * 4), ("busy_lane_iterations", C.c_uint64), ("cycles_steps", C.c_uint64),
                 ("bvh_width", C.c_int32), ("frames", C.c_int32),
-                ("search_queue_peak", C.c_int32), ("search_queue_size", C.c_int32), ("stack_overflow_steps", C.c_uint64)]
+                ("search_queue_peak", C.c_int32), ("search_queue_size", C.c_int32),
+                ("bvh_node_bytes", C.c_int32), ("reserved0", C.c_int32), ("stack_overflow_steps", C.c_uint64)]
 
 
 class RtSceneView(C.Structure):

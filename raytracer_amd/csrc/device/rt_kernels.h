@@ -10,7 +10,7 @@ namespace rtd {
 struct DeviceScene {
     const float4* prims_bvh;   // 3 float4 per primitive, BVH leaf order
     const float4* prims_flat;  // 3 float4 per primitive, the reference's loop order
-    const float4* nodes;       // 4 float4 per BVH node, node 0 = root (the pooled kernel's four-wide search: 8 float4 per node)
+    const float4* nodes;       // 4 float4 per BVH node, node 0 = root (four-wide search: 8 float4 per node, or 5 in the 80-byte form)
     const float4* materials;   // 5 float4 per material (raytracer.comp:54-82)
     const float4* lights;      // 3 float4 per light    (raytracer.comp:47-52)
     const float4* triangles;   // 4 float4 per triangle (raytracer.comp:90-96), for stored normals and light sampling
@@ -113,7 +113,8 @@ int pool_slots_per_block();
 int pool_overflow_per_lane();  // the least a lane's overflow area holds; a four-wide tree may need more (pool_overflow_for)
 int pool_overflow_for(int stack_need);  // words per lane for a tree whose traversal holds up to stack_need entries
 int pool_threads_per_block();
-// accel: 0 the flat loops, 1 the binary tree, 2 the four-wide tree (sc.nodes must then be the wide nodes)
+// accel: 0 the flat loops, 1 the binary tree, 2 the four-wide tree in 128-byte nodes, 3 in 80-byte nodes (sc.nodes must
+// then be the nodes of that form)
 // per_cu_cap > 0 limits the workgroups per CU below what fits (tuning aid); accel / stats / batch / shader_waves name
 // the kernel instance launch_pool will pick (batch: a launch of several frames), whose occupancy is asked for
 hipError_t pool_grid(const FrameArgs& fa, int accel, bool stats, bool batch, int shader_waves, int cu_count, int per_cu_cap, unsigned* grid);

@@ -40,7 +40,7 @@ RT_DEV void trace_bvh_steps(const DeviceScene& sc, V3 ro, V3 rd, const LdsStack 
         if (STATS) wave_iters++;
         if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
             if (tv.cur >= 0 && tv.cur != kTravDone) {
-                if (WIDE) trav_wide_step(sc.nodes, sl, stack, tv);
+                if (WIDE) trav_wide_step<false>(sc.nodes, sl, stack, tv);
                 else trav_node_step(sc.nodes, sl, stack, tv);
                 if (STATS) { n_nodes++; n_iters++; }
             }

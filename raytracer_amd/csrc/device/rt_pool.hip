@@ -630,7 +630,8 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 if ((int)__popcll(m_node) >= (int)__popcll(m_leaf)) {
                     if (tv.cur >= 0 && tv.cur != kTravDone) {
                         const int sp_before = tv.sp;
-                        if (ACCEL == 2) trav_wide_step(sc.nodes, sl, stack, tv);
+                        if (ACCEL == 3) trav_wide_step<true>(sc.nodes, sl, stack, tv);
+                        else if (ACCEL == 2) trav_wide_step<false>(sc.nodes, sl, stack, tv);
                         else trav_node_step(sc.nodes, sl, stack, tv);
                         if (STATS) n_nodes++;
                         if (STATS && tv.sp > sp_before && tv.sp > kShortStack) overflow_steps++;
@@ -689,10 +690,15 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
 typedef void (*PoolKernel)(DeviceScene, FrameArgs, PathPool, int, int, int, int, int);
 template <bool BATCH>
 PoolKernel pick_kernel_of(int accel, bool stats) {
+    if (accel == 3) return stats ? pool_kernel<3, true, BATCH> : pool_kernel<3, false, BATCH>;
     if (accel == 2) return stats ? pool_kernel<2, true, BATCH> : pool_kernel<2, false, BATCH>;
     return accel == 1 ? (stats ? pool_kernel<1, true, BATCH> : pool_kernel<1, false, BATCH>) : (stats ? pool_kernel<0, true, BATCH> : pool_kernel<0, false, BATCH>);
 }
 PoolKernel pick_kernel(int accel, bool stats, bool batch = false, int shader_waves = 0) {
+    if (accel == 3 && !stats) {  // the 80-byte nodes are for scenes beyond the caches, which run with two shading waves
+        if (!batch && shader_waves == 2) return pool_kernel<3, false, false, 2>;
+        if (batch && shader_waves == 2) return pool_kernel<3, false, true, 2>;
+    }
     if (accel == 2 && !stats) {  // the instances with the shading waves compiled in
         if (!batch && shader_waves == 3) return pool_kernel<2, false, false, 3>;
         if (!batch && shader_waves == 2) return pool_kernel<2, false, false, 2>;

@@ -183,25 +183,50 @@ RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, con
     else trav_pop(tv, stack);
 }
 
-// The same for a four-wide node (8 float4: centre x, y, z and half extent x, y, z of the four children, their
-// cursor words, padding): slab-test the four children, descend into the nearest one hit, push the others,
+// The same for a four-wide node: slab-test the four children, descend into the nearest one hit, push the others,
 // farthest first.  With centre and half extent the entry and exit distances need no min / max per axis:
 // (c * inv + off) -+ h * |inv|.  An empty place has a negative half extent: its entry lies behind its exit.
 // The boxes are padded on the host by 5e-6 of the scene's scale, five times what the rounding of these sums and of the
 // reciprocal can amount to for rays that start inside the scene (host/bvh_builder.cpp).
-template <typename Stack>
+// Two node formats (rt::WideNode, rt::WideNode16): HALF = false, 128 bytes - centre x, y, z and half extent x, y, z of the
+// four children in binary32, their cursor words: seven 16-byte loads; HALF = true, 80 bytes back to back - a point of
+// the node in binary32, centres relative to it and half extents in binary16, cursor words: five loads, three more
+// multiply-adds (the node's point through the slab constants), the halves widened inside v_fma_mix_f32.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+RT_DEV float half_lo(float packed) { return (float)__builtin_bit_cast(half2_t, packed).x; }
+RT_DEV float half_hi(float packed) { return (float)__builtin_bit_cast(half2_t, packed).y; }
+struct Quad { float x, y, z, w; };
+template <bool HALF, typename Stack>
 RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
-    const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;
-    const float4 cx = nd[0], cy = nd[1], cz = nd[2];
-    const float4 hx = nd[3], hy = nd[4], hz = nd[5];
-    const float4 w = nd[6];
+    Quad cx, cy, cz, hx, hy, hz;
+    float4 w;
+    float ox, oy, oz;  // the slab offsets the centres are taken against
+    if (HALF) {
+        const float4* __restrict__ nd = nodes + 5 * (size_t)tv.cur;
+        const float4 org = nd[0], qa = nd[1], qb = nd[2], qc = nd[3];
+        w = nd[4];
+        ox = __builtin_fmaf(org.x, sl.ix, sl.ox); oy = __builtin_fmaf(org.y, sl.iy, sl.oy); oz = __builtin_fmaf(org.z, sl.iz, sl.oz);
+        cx = {half_lo(qa.x), half_hi(qa.x), half_lo(qa.y), half_hi(qa.y)};
+        cy = {half_lo(qa.z), half_hi(qa.z), half_lo(qa.w), half_hi(qa.w)};
+        cz = {half_lo(qb.x), half_hi(qb.x), half_lo(qb.y), half_hi(qb.y)};
+        hx = {half_lo(qb.z), half_hi(qb.z), half_lo(qb.w), half_hi(qb.w)};
+        hy = {half_lo(qc.x), half_hi(qc.x), half_lo(qc.y), half_hi(qc.y)};
+        hz = {half_lo(qc.z), half_hi(qc.z), half_lo(qc.w), half_hi(qc.w)};
+    } else {
+        const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;
+        const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3], e = nd[4], f = nd[5];
+        w = nd[6];
+        cx = {a.x, a.y, a.z, a.w}; cy = {b.x, b.y, b.z, b.w}; cz = {c.x, c.y, c.z, c.w};
+        hx = {d.x, d.y, d.z, d.w}; hy = {e.x, e.y, e.z, e.w}; hz = {f.x, f.y, f.z, f.w};
+        ox = sl.ox; oy = sl.oy; oz = sl.oz;
+    }
     float t0, t1, t2, t3;
     int c0 = __float_as_int(w.x), c1 = __float_as_int(w.y), c2 = __float_as_int(w.z), c3 = __float_as_int(w.w);
     const float ax = __builtin_fabsf(sl.ix), ay = __builtin_fabsf(sl.iy), az = __builtin_fabsf(sl.iz);
 #define RT_WIDE_CHILD(T, F)                                                                                  \
     {                                                                                                         \
-        const float bx = __builtin_fmaf(cx.F, sl.ix, sl.ox), by = __builtin_fmaf(cy.F, sl.iy, sl.oy);       \
-        const float bz = __builtin_fmaf(cz.F, sl.iz, sl.oz);                                                \
+        const float bx = __builtin_fmaf(cx.F, sl.ix, ox), by = __builtin_fmaf(cy.F, sl.iy, oy);             \
+        const float bz = __builtin_fmaf(cz.F, sl.iz, oz);                                                   \
         const float nx = __builtin_fmaf(-hx.F, ax, bx), ny = __builtin_fmaf(-hy.F, ay, by), nz = __builtin_fmaf(-hz.F, az, bz); \
         const float fx = __builtin_fmaf(hx.F, ax, bx), fy = __builtin_fmaf(hy.F, ay, by), fz = __builtin_fmaf(hz.F, az, bz);    \
         const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);                                           \

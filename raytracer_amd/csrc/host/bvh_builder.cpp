@@ -501,8 +501,80 @@ void child_refs(const BvhNode& n, std::vector<WideRef>& out) {
 }
 }  // namespace
 
+namespace {
+// binary32 -> binary16 bits, round to nearest even (up = false) or towards +infinity (up = true), for finite values
+// below binary16's largest (the caller checks); results that would be subnormal are flushed: to zero when rounding to
+// nearest, to the smallest normal number when rounding up (positive values) or to zero (negative ones).
+uint16_t to_half(float f, bool up) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const bool neg = sign != 0;
+    if ((x & 0x7fffffffu) == 0) return (uint16_t)sign;
+    const int32_t e = (int32_t)((x >> 23) & 0xffu) - 127 + 15;
+    if (e <= 0) return (uint16_t)((up && !neg) ? 0x0400u : sign);
+    const uint32_t m = x & 0x7fffffu;
+    uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rest = m & 0x1fffu;
+    if (up) {
+        if (rest != 0 && !neg) h += 1;  // towards +inf: positive values grow, negative ones are truncated
+    } else if (rest > 0x1000u || (rest == 0x1000u && (h & 1u))) {
+        h += 1;
+    }
+    return (uint16_t)(sign | h);
+}
+double from_half(uint16_t h) {
+    const int s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 0x3ff;
+    const double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(m | 0x400), e - 25);
+    return s ? -v : v;
+}
+const float kHalfMax = 65000.0f;
+
+// The 80-byte form of a wide node (see WideNode16).  False if a value does not fit binary16's range.
+bool make_node16(const WideNode& w, WideNode16& o) {
+    std::memset(&o, 0, sizeof o);
+    const float* cc[3] = {w.cx, w.cy, w.cz};
+    const float* hh[3] = {w.hx, w.hy, w.hz};
+    for (int a = 0; a < 3; ++a) {
+        float lo = kInf, hi = -kInf;
+        for (int k = 0; k < 4; ++k) {
+            if (w.child[k] == kWideUnused) continue;
+            lo = std::fmin(lo, cc[a][k] - hh[a][k]);
+            hi = std::fmax(hi, cc[a][k] + hh[a][k]);
+        }
+        o.origin[a] = lo <= hi ? 0.5f * lo + 0.5f * hi : 0.0f;
+        if (!std::isfinite(o.origin[a])) return false;
+    }
+    for (int k = 0; k < 4; ++k) {
+        o.child[k] = w.child[k];
+        for (int a = 0; a < 3; ++a) {
+            if (w.child[k] == kWideUnused) {
+                o.c[a][k] = 0;
+                o.h[a][k] = 0xbc00u;  // -1: entry behind exit for every ray
+                continue;
+            }
+            const float crel = cc[a][k] - o.origin[a];
+            if (!(std::fabs(crel) < kHalfMax)) return false;
+            o.c[a][k] = to_half(crel, false);
+            // the box the binary32 node stands for, as real numbers, inside origin + c16 -+ h16
+            const double c = (double)o.origin[a] + from_half(o.c[a][k]);
+            const double blo = (double)cc[a][k] - (double)hh[a][k], bhi = (double)cc[a][k] + (double)hh[a][k];
+            const double need = std::fmax(bhi - c, c - blo);
+            if (!(need < (double)kHalfMax)) return false;
+            uint16_t h16 = to_half((float)need, true);
+            if ((h16 & 0x7c00u) == 0) h16 = 0x0400u;                   // never zero or subnormal
+            while (from_half(h16) < need) h16 = (uint16_t)(h16 + 1);  // (float)need may have rounded down
+            o.h[a][k] = h16;
+        }
+    }
+    return true;
+}
+}  // namespace
+
 void collapse_wide(const HostBvh& bvh, HostWideBvh& out) {
     out.nodes.clear();
+    out.nodes16.clear();
+    out.half_ok = false;
     out.stack_need = 0;
     out.depth = 0;
     if (bvh.nodes.empty()) return;
@@ -561,6 +633,10 @@ void collapse_wide(const HostBvh& bvh, HostWideBvh& out) {
         }
         out.nodes[(size_t)t.wide] = w;
     }
+    out.nodes16.resize(out.nodes.size());
+    out.half_ok = true;
+    for (size_t i = 0; i < out.nodes.size() && out.half_ok; ++i) out.half_ok = make_node16(out.nodes[i], out.nodes16[i]);
+    if (!out.half_ok) out.nodes16.clear();
 }
 
 bool validate_wide(const HostBvh& bvh, const HostWideBvh& wide, std::string* err) {
@@ -604,6 +680,30 @@ bool validate_wide(const HostBvh& bvh, const HostWideBvh& wide, std::string* err
                 if ((size_t)c >= wide.nodes.size() || seen[(size_t)c]) return fail(err, "wide node index out of range or reached twice");
                 seen[(size_t)c] = 1;
                 stack.push_back({c, held, it.depth + 1});
+            }
+        }
+    }
+    if (wide.half_ok) {
+        // the 80-byte form: same children, and every child's box contains the box of the 128-byte form
+        if (wide.nodes16.size() != wide.nodes.size()) return fail(err, "the two forms of the wide tree differ in size");
+        for (size_t i = 0; i < wide.nodes.size(); ++i) {
+            const WideNode& w = wide.nodes[i];
+            const WideNode16& q = wide.nodes16[i];
+            const float* cc[3] = {w.cx, w.cy, w.cz};
+            const float* hh[3] = {w.hx, w.hy, w.hz};
+            for (int k = 0; k < 4; ++k) {
+                if (q.child[k] != w.child[k]) return fail(err, "the two forms of a wide node name different children");
+                for (int a = 0; a < 3; ++a) {
+                    const double c = (double)q.origin[a] + from_half(q.c[a][k]), h = from_half(q.h[a][k]);
+                    if (w.child[k] == kWideUnused) {
+                        if (!(h < 0.0)) return fail(err, "empty child of an 80-byte node can be entered");
+                        continue;
+                    }
+                    if ((q.h[a][k] & 0x7c00u) == 0 || ((q.c[a][k] & 0x7fffu) != 0 && (q.c[a][k] & 0x7c00u) == 0))
+                        return fail(err, "subnormal binary16 in a node");
+                    if (c - h > (double)cc[a][k] - (double)hh[a][k] || c + h < (double)cc[a][k] + (double)hh[a][k])
+                        return fail(err, "80-byte node's box does not contain the 128-byte node's");
+                }
             }
         }
     }

@@ -88,9 +88,28 @@ struct WideNode {
 static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 static const int32_t kWideUnused = 0x7fffffff;
 
+// The same node in 80 bytes, for scenes whose trees do not fit the caches (five 16-byte loads per visit instead of
+// seven, 5/8 of the bytes): a point of the node (binary32), the children's box centres RELATIVE to it and their half
+// extents in binary16, the cursor words.  The half extents are rounded up until origin + centre -+ half extent (as real
+// numbers) contain the binary tree's box, so the traversal still tests a superset of the binary traversal's leaves; a
+// binary16 carries 11 significant bits of a distance that is at most the node's own extent, so the boxes grow by less
+// than a thousandth of the node's size.  Subnormal binary16 values are not used (a centre that would be one is stored as
+// zero, a half extent as the smallest normal number), so the result does not depend on how the device treats them.
+// The device widens the halves inside its fused multiply-adds (v_fma_mix_f32): no conversion instructions.
+struct WideNode16 {
+    float origin[3];
+    float pad;
+    uint16_t c[3][4];   // centre - origin: x of the four children, y, z
+    uint16_t h[3][4];   // half extent (negative for an empty place)
+    int32_t child[4];
+};
+static_assert(sizeof(WideNode16) == 80, "WideNode16 must be 80 bytes");
+
 struct HostWideBvh {
-    std::vector<WideNode> nodes;  // nodes[0] is the root
-    int32_t stack_need = 0;       // most entries a traversal can hold at once (every node on a path entered through all its children)
+    std::vector<WideNode> nodes;      // nodes[0] is the root
+    std::vector<WideNode16> nodes16;  // the same nodes, same indices, in the 80-byte form (empty if half_ok is false)
+    bool half_ok = false;             // every relative centre and half extent fits binary16's range
+    int32_t stack_need = 0;           // most entries a traversal can hold at once (every node on a path entered through all its children)
     int32_t depth = 0;
 };
 

@@ -66,7 +66,7 @@ struct FrameScratch {
 };
 
 void free_scene(RtContext* c) {
-    void** ptrs[] = {&c->d_prims_bvh, &c->d_prims_flat, &c->d_nodes, &c->d_nodes_wide, &c->d_materials, &c->d_lights, &c->d_triangles};
+    void** ptrs[] = {&c->d_prims_bvh, &c->d_prims_flat, &c->d_nodes, &c->d_nodes_wide, &c->d_nodes_wide16, &c->d_materials, &c->d_lights, &c->d_triangles};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -218,6 +218,8 @@ int upload_built(RtContext* c, const BuiltScene& b) {
     if ((rc = upload_array(c, &c->d_prims_flat, b.flat.data(), b.flat.size() * sizeof(rt::PrimRecord), 48)) != RT_OK) return bail(rc);
     if ((rc = upload_array(c, &c->d_nodes, b.dev_nodes.data(), b.dev_nodes.size() * sizeof(rt::BvhNode), 64)) != RT_OK) return bail(rc);
     if ((rc = upload_array(c, &c->d_nodes_wide, b.wide.nodes.data(), b.wide.nodes.size() * sizeof(rt::WideNode), 128)) != RT_OK) return bail(rc);
+    if (b.wide.half_ok && (rc = upload_array(c, &c->d_nodes_wide16, b.wide.nodes16.data(), b.wide.nodes16.size() * sizeof(rt::WideNode16) + 48, 128)) != RT_OK)
+        return bail(rc);  // (+ 48: the last node's fifth 16-byte load ends inside the allocation whatever its alignment)
     if ((rc = upload_array(c, &c->d_materials, b.materials, (size_t)b.n_materials * sizeof(RtMaterial), sizeof(RtMaterial))) != RT_OK) return bail(rc);
     if ((rc = upload_array(c, &c->d_lights, b.lights, (size_t)b.n_lights * sizeof(RtLight), sizeof(RtLight))) != RT_OK) return bail(rc);
     if ((rc = upload_array(c, &c->d_triangles, b.triangles, (size_t)b.n_triangles * sizeof(RtTriangle), sizeof(RtTriangle))) != RT_OK) return bail(rc);
@@ -294,7 +296,7 @@ int rt_create(int device_ordinal, RtContext** out_ctx) {
         {"RT_EXIT_QUOTA_PCT", RT_OPT_EXIT_QUOTA_PCT}, {"RT_REFILL_MIN", RT_OPT_REFILL_MIN}, {"RT_POOL_BURST", RT_OPT_POOL_BURST},
         {"RT_POOL_JOB_MIN", RT_OPT_POOL_JOB_MIN}, {"RT_TILE_CLASSES", RT_OPT_TILE_CLASSES}, {"RT_POOL_PER_CU", RT_OPT_POOL_PER_CU},
         {"RT_MAX_LEAF", RT_OPT_BVH_MAX_LEAF}, {"RT_POOL_SLOTS", RT_OPT_POOL_SLOTS}, {"RT_BVH_TREELET", RT_OPT_BVH_TREELET},
-        {"RT_BVH_WIDTH", RT_OPT_BVH_WIDTH}, {"RT_POOL_SHADER_WAVES", RT_OPT_POOL_SHADER_WAVES}};
+        {"RT_BVH_WIDTH", RT_OPT_BVH_WIDTH}, {"RT_POOL_SHADER_WAVES", RT_OPT_POOL_SHADER_WAVES}, {"RT_BVH_NODE_FORMAT", RT_OPT_BVH_NODE_FORMAT}};
     for (const auto& e : env)
         if (const char* v = getenv(e.name)) (void)rt_set_option(c, e.option, atoi(v));  // out-of-range values are ignored
     *out_ctx = c;
@@ -490,6 +492,17 @@ static int pooled_bvh_width(const RtContext* c, int overflow_words) {
     if (c->wide_nodes <= 0 || rtd::pool_overflow_for(c->wide_stack_need) > overflow_words) return 2;
     return c->opt.bvh_width != 0 ? c->opt.bvh_width : 4;
 }
+// Node format of the four-wide tree for the pooled kernel.  The 80-byte nodes (binary16 boxes relative to a point of
+// the node) take five 16-byte loads per visit instead of seven and three more multiply-adds: where the tree does not
+// fit the caches the fetch path is what the vector pipes wait for (1.07 M triangles, 16 frames per launch: L1 / texture
+// path 71 % busy, 80 % of the issue slots used -> 60 % / 87 %, 9.28 -> 8.60 ms per frame; a frame alone 10.99 -> 10.55), where
+// it does fit they are pure cost (teapot scene 6.77 -> 6.88 ms, star scene 2.24 -> 2.28).  Same bits either way.
+static bool pooled_half_nodes(const RtContext* c) {
+    if (!c->d_nodes_wide16) return false;
+    if (c->opt.bvh_node_format != 0) return c->opt.bvh_node_format == 16;
+    const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
+    return scene_bytes > ((size_t)16 << 20);
+}
 // Search steps of a pooled wave between two looks at the queues: about as many as a ray takes, so that few
 // lanes sit finished through the rest of a burst.  Four-wide tree, 1080p: the small scenes' rays take 6 lane steps
 // in 7-8 wave steps (burst 6: 7.08 ms, 7: 7.00, 8: 7.01, 9: 7.07, 10: 7.11, 12: 7.28 on the teapot scene; 8 also
@@ -542,9 +555,12 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
             rtd::DeviceScene sc = sc_in;
             int accel = p.accel;
             const int width = pooled_bvh_width(c, overflow_words);
+            c->last_node_bytes = p.accel == RT_ACCEL_BVH ? 64 : 0;
             if (accel == RT_ACCEL_BVH && width == 4) {
-                accel = 2;
-                sc.nodes = (const float4*)c->d_nodes_wide;
+                const bool half = pooled_half_nodes(c);
+                accel = half ? 3 : 2;
+                sc.nodes = (const float4*)(half ? c->d_nodes_wide16 : c->d_nodes_wide);
+                c->last_node_bytes = half ? 80 : 128;
             }
             c->last_width = p.accel == RT_ACCEL_BVH ? width : 0;
             RT_HIP(c, rtd::launch_pool(sc, fa, pp, accel, stats, grid, c->opt.refill_min, pool_burst(c, width), pool_job_min(c, fa.n_frames), pool_slots(c, fa.n_frames),
@@ -558,6 +574,7 @@ static int launch_frame(RtContext* c, const rtd::DeviceScene& sc_in, const rtd::
                 sc.nodes = (const float4*)c->d_nodes_wide;
             }
             c->last_width = p.accel == RT_ACCEL_BVH ? (accel == 2 ? 4 : 2) : 0;
+            c->last_node_bytes = p.accel == RT_ACCEL_BVH ? (accel == 2 ? 128 : 64) : 0;
             RT_HIP(c, rtd::launch_render(sc, fa, accel, stats, c->cu_count, c->stream));
         }
     }
@@ -675,7 +692,7 @@ static int render_impl(RtContext* c, const RtCamera* camera, const RtPushConstan
     }
     unsigned grid = 0;
     if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
-        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, pooled_overflow_words(c)) == 4 ? 2 : 1) : 0, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0,
+        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, pooled_overflow_words(c)) == 4 ? (pooled_half_nodes(c) ? 3 : 2) : 1) : 0, (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0,
                                  n_frames > 1, pool_shader_waves(c, n_frames), c->cu_count, c->opt.pool_per_cu, &grid));
         rc = ensure_pool_bytes(c, pooled_pool_bytes(grid, pooled_overflow_words(c)));
         if (rc != RT_OK) return rc;
@@ -789,7 +806,7 @@ int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushCo
     }
     unsigned grid = 0;
     if (pipeline == RT_PIPELINE_POOLED && fa.total_slots > 0) {
-        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, rtd::pool_overflow_per_lane()) == 4 ? 2 : 1) : 0,
+        RT_HIP(c, rtd::pool_grid(fa, p.accel == RT_ACCEL_BVH ? (pooled_bvh_width(c, rtd::pool_overflow_per_lane()) == 4 ? (pooled_half_nodes(c) ? 3 : 2) : 1) : 0,
                                  (p.flags & RT_FLAG_TRAVERSAL_STATS) != 0, false, pool_shader_waves(c, 1), c->cu_count, c->opt.pool_per_cu, &grid));
         const unsigned fits = (unsigned)(kScratchPoolBytes / pooled_pool_bytes(1, rtd::pool_overflow_per_lane()));
         grid = grid > fits ? fits : grid;  // fewer workgroups than CUs still render the whole frame
@@ -810,10 +827,11 @@ int rt_set_option(RtContext* c, int option, int value) {
         {RT_OPT_TILE_CLASSES, &c->opt.tile_classes, 1, 64},      {RT_OPT_POOL_PER_CU, &c->opt.pool_per_cu, 0, 8},
         {RT_OPT_BVH_MAX_LEAF, &c->opt.bvh_max_leaf, 1, 8},       {RT_OPT_POOL_SLOTS, &c->opt.pool_slots, 0, rtd::pool_slots_per_block()},
         {RT_OPT_BVH_TREELET, &c->opt.bvh_treelet, 0, 16},        {RT_OPT_BVH_WIDTH, &c->opt.bvh_width, 0, 4},
-        {RT_OPT_POOL_SHADER_WAVES, &c->opt.pool_shader_waves, 0, 9}};
+        {RT_OPT_POOL_SHADER_WAVES, &c->opt.pool_shader_waves, 0, 9}, {RT_OPT_BVH_NODE_FORMAT, &c->opt.bvh_node_format, 0, 32}};
     for (const auto& t : table) {
         if (t.option != option) continue;
-        if (value < t.lo || value > t.hi || (option == RT_OPT_BVH_WIDTH && (value == 1 || value == 3)))
+        if (value < t.lo || value > t.hi || (option == RT_OPT_BVH_WIDTH && (value == 1 || value == 3)) ||
+            (option == RT_OPT_BVH_NODE_FORMAT && value != 0 && value != 16 && value != 32))
             return fail(c, RT_ERR_INVALID_ARGUMENT, "option value out of range");
         *t.field = value;
         return RT_OK;
@@ -891,6 +909,7 @@ int rt_get_stats(RtContext* c, RtStats* out) {
     out->total_prims = c->n_prims;
     out->pipeline = c->last_pipeline;
     out->bvh_width = c->last_width;
+    out->bvh_node_bytes = c->last_node_bytes;
     out->frames = c->last_frames;
     return rtapi::check_abandoned(c);
 }

@@ -24,6 +24,7 @@ struct RtOptions {
     int bvh_max_leaf = 4;     // builder: most primitives per leaf (takes effect at the next rt_upload_scene)
     int bvh_width = 0;        // pooled kernel: children per node of the tree it walks (2, 4; 0: four when its stack fits)
     int bvh_treelet = 0;      // node layout: levels per treelet (0 / 1: depth-first order; next rt_upload_scene)
+    int bvh_node_format = 0;  // pooled kernel, four-wide tree: 32 = 128-byte nodes, 16 = 80-byte nodes with binary16 boxes; 0: by scene size
 };
 
 struct RtContext {
@@ -36,6 +37,7 @@ struct RtContext {
     int32_t last_pipeline = 0;
     int32_t last_frames = 1;  // frames rendered by the last launch (rt_render_frames)
     int32_t last_width = 0;  // children per node of the tree the last frame's kernel walked (0: the flat loops)
+    int32_t last_node_bytes = 0;  // bytes per node of that tree
     RtOptions opt;
 
     // scene
@@ -44,6 +46,7 @@ struct RtContext {
     void* d_prims_flat = nullptr;
     void* d_nodes = nullptr;
     void* d_nodes_wide = nullptr;  // the four-wide form of the same tree (pooled kernel)
+    void* d_nodes_wide16 = nullptr;  // ... in 80-byte nodes (null if the scene's coordinates do not fit binary16 offsets)
     void* d_materials = nullptr;
     void* d_lights = nullptr;
     void* d_triangles = nullptr;

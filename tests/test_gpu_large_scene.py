@@ -69,17 +69,22 @@ def grid_oracle(grid):
     return oracle_frames(grid, W, H, spp=1, max_bounces=3, frames=2, camera=workload_camera("c5", W, H), threads=16)
 
 
-@pytest.mark.parametrize("pipeline,width", [(capi.RT_FLAG_SINGLE_KERNEL, 2), (capi.RT_FLAG_POOLED, 2), (capi.RT_FLAG_POOLED, 4)])
-def test_teapot_grid_against_the_oracle(ctx, grid, grid_oracle, pipeline, width):
+@pytest.mark.parametrize("pipeline,width,node_format,node_bytes", [(capi.RT_FLAG_SINGLE_KERNEL, 2, 0, 64), (capi.RT_FLAG_POOLED, 2, 0, 64),
+                                                                   (capi.RT_FLAG_POOLED, 4, 0, 80), (capi.RT_FLAG_POOLED, 4, 32, 128)])
+def test_teapot_grid_against_the_oracle(ctx, grid, grid_oracle, pipeline, width, node_format, node_bytes):
     """1 068 084 primitives, the benchmark's camera, two accumulated frames: the single kernel (binary tree: the wide
-    one's stack does not fit its LDS) and the pooled kernel on both tree widths against the oracle's flat loops."""
+    one's stack does not fit its LDS) and the pooled kernel on the binary tree and on the four-wide one in both node
+    formats (left to itself it reads a scene of this size in 80-byte nodes with binary16 boxes) against the oracle's
+    flat loops."""
     W, H = 48, 27
     try:
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, width)
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, node_format)
         g = frames_of(ctx, grid, W, H, spp=1, max_bounces=3, frames=2, camera=workload_camera("c5", W, H), flags=DEBUG_FLAGS | pipeline)
     finally:
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, 0)
-    assert g["stats"].bvh_width == width
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 0)
+    assert g["stats"].bvh_width == width and g["stats"].bvh_node_bytes == node_bytes
     assert g["stats"].pipeline == (capi.RT_PIPELINE_POOLED if pipeline == capi.RT_FLAG_POOLED else capi.RT_PIPELINE_SINGLE)
     assert_identical_but_edge_ties(g, grid_oracle)
     assert (grid_oracle["primary_ids"] >= 4).mean() > 0.3  # a good part of the frame sees teapots (ids 0-3 are floor and lamp)
@@ -126,14 +131,20 @@ def grid_flat_240(ctx, grid):
     return frames_of(ctx, grid, W, H, spp=2, max_bounces=6, camera=workload_camera("c5", W, H), accel=capi.RT_ACCEL_FLAT)
 
 
-@pytest.mark.parametrize("pipeline", [capi.RT_FLAG_SINGLE_KERNEL, capi.RT_FLAG_POOLED])
-def test_teapot_grid_tree_search_equals_flat_search_at_a_larger_size(ctx, grid, grid_flat_240, pipeline):
+@pytest.mark.parametrize("pipeline,node_format", [(capi.RT_FLAG_SINGLE_KERNEL, 0), (capi.RT_FLAG_POOLED, 0), (capi.RT_FLAG_POOLED, 32)])
+def test_teapot_grid_tree_search_equals_flat_search_at_a_larger_size(ctx, grid, grid_flat_240, pipeline, node_format):
     """Too large for the oracle: the device's flat search (bit-identical to the oracle wherever that is checked) against
     its tree search, 240x135, 2 spp, 6 bounces, every output; the edge-tie pixels are listed."""
     W, H = 240, 135
     cam = workload_camera("c5", W, H)
     f = grid_flat_240
-    b = frames_of(ctx, grid, W, H, spp=2, max_bounces=6, camera=cam, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
+    try:
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, node_format)
+        b = frames_of(ctx, grid, W, H, spp=2, max_bounces=6, camera=cam, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
+    finally:
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 0)
+    if pipeline == capi.RT_FLAG_POOLED:
+        assert b["stats"].bvh_node_bytes == (128 if node_format == 32 else 80)
     bad = assert_identical_but_edge_ties(b, f)
     same = bit_equal_pixels(b["accum"], f["accum"]) & (b["path_hash"] == f["path_hash"])
     ties = [{"x": int(x), "y": int(y), "primary_id_bvh": int(b["primary_ids"][y, x]), "primary_id_flat": int(f["primary_ids"][y, x])}
@@ -141,7 +152,7 @@ def test_teapot_grid_tree_search_equals_flat_search_at_a_larger_size(ctx, grid, 
     print(f"edge-tie pixels at {W}x{H}, 2 spp, 6 bounces, 1.07 M-triangle scene: {bad} {ties}")
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        name = "pooled" if pipeline == capi.RT_FLAG_POOLED else "single"
+        name = ("pooled" if pipeline == capi.RT_FLAG_POOLED else "single") + ("_nodes128" if node_format == 32 else "")
         with open(os.path.join(out, f"edge_ties_teapot_grid_{name}_240x135.json"), "w") as fh:
             json.dump({"width": W, "height": H, "spp": 2, "max_bounces": 6, "scene": "teapot_grid", "pixels": ties}, fh)
 
@@ -176,6 +187,8 @@ def test_scene_of_36_meshes_beyond_the_builders_parallel_threshold(ctx, pipeline
     o = oracle_frames(s, W, H, spp=1, max_bounces=4, camera=cam, threads=16)
     g = frames_of(ctx, s, W, H, spp=1, max_bounces=4, camera=cam, flags=DEBUG_FLAGS | pipeline)
     assert_identical_but_edge_ties(g, o)
+    if pipeline == capi.RT_FLAG_POOLED:
+        assert g["stats"].bvh_node_bytes == 80  # beyond 16 MB: binary16 boxes
     seen = o["primary_ids"][o["primary_ids"] >= 4]  # ids 0-3: floor and lamp; mesh m's triangles follow at 4 + 6320 m
     assert len(np.unique((seen - 4) // 6320)) > 10  # many of the meshes are seen
     f = frames_of(ctx, s, W, H, spp=1, max_bounces=4, camera=cam, accel=capi.RT_ACCEL_FLAT)

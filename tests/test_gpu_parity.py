@@ -373,24 +373,34 @@ def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, st
 @pytest.mark.parametrize("kind", ["teapot", "mixed"])
 def test_tree_widths_agree(ctx, teapot, kind, pipeline):
     """Both kernels walk the four-wide form of the tree unless told otherwise (RT_OPT_BVH_WIDTH) or its stack
-    does not fit: both widths hold the same leaves behind boxes that contain them, so they must agree bit for
-    bit - with each other, and (but for edge ties) with the oracle."""
+    does not fit, and the pooled kernel reads it in 128-byte nodes or in 80-byte nodes with binary16 boxes
+    (RT_OPT_BVH_NODE_FORMAT; by itself only on scenes beyond 16 MB): every form holds the same leaves behind boxes that
+    contain them, so they must agree bit for bit - with each other, and (but for edge ties) with the oracle."""
     from helpers import DEBUG_FLAGS
     W, H = 120, 68
     s = teapot if kind == "teapot" else _custom_scene(kind)
     o = oracle_frames(s, W, H, spp=2, max_bounces=5)
     got = {}
+    pooled = pipeline == capi.RT_FLAG_POOLED
     try:
-        for width in (2, 4):
+        for width, fmt in ((2, 0), (4, 32), (4, 16), (4, 0)):
             ctx.set_option(capi.RT_OPT_BVH_WIDTH, width)
-            got[width] = gpu_frames(ctx, s, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
-            assert got[width]["stats"].bvh_width == width
+            ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, fmt)
+            got[width, fmt] = gpu_frames(ctx, s, W, H, spp=2, max_bounces=5, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | pipeline)
+            st = got[width, fmt]["stats"]
+            assert st.bvh_width == width
+            # (the single kernel has the 128-byte form only; a scene this small gets it from the pooled kernel too unless asked)
+            assert st.bvh_node_bytes == (64 if width == 2 else 80 if (fmt == 16 and pooled) else 128)
     finally:
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, 0)
-    assert_identical(got[4], got[2])
-    assert_identical_but_edge_ties(got[4], o)
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 0)
+    for key in ((4, 32), (4, 16), (4, 0)):
+        assert_identical(got[key], got[2, 0])
+    assert_identical_but_edge_ties(got[4, 16], o)
     with pytest.raises(Exception):
         ctx.set_option(capi.RT_OPT_BVH_WIDTH, 3)
+    with pytest.raises(Exception):
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 8)
 
 
 @pytest.mark.parametrize("kind", ["empty", "one_sphere", "one_triangle", "three"])
