@@ -308,7 +308,7 @@ enum { RT_OPT_EXIT_QUOTA_PCT = 1, /* single kernel: leave the search loop once t
        RT_OPT_POOL_SHADER_WAVES = 11, /* pooled kernel: waves of a workgroup's 16 that only shade (1..8; 9 = none; 0 = by scene) */
        RT_OPT_BVH_NODE_FORMAT = 12 }; /* pooled kernel, four-wide tree: 32 = 128-byte nodes (binary32 boxes), 16 = 80-byte nodes
                                        (binary16 boxes relative to a point of the node, rounded outwards: same results, fewer
-                                       bytes fetched per visit); 0 = 16 for scenes beyond 16 MB, else 32                     */
+                                       bytes fetched per visit); 0 = 16 for scenes beyond 4 MB (one XCD's L2), else 32          */
 int rt_set_option(RtContext* ctx, int option, int value);
 /* Device pointers of the live framebuffer (for zero-copy use by a collective library). */
 int rt_get_device_buffers(RtContext* ctx, void** d_accum, void** d_counts, void** d_bgra8);

@@ -695,8 +695,10 @@ PoolKernel pick_kernel_of(int accel, bool stats) {
     return accel == 1 ? (stats ? pool_kernel<1, true, BATCH> : pool_kernel<1, false, BATCH>) : (stats ? pool_kernel<0, true, BATCH> : pool_kernel<0, false, BATCH>);
 }
 PoolKernel pick_kernel(int accel, bool stats, bool batch = false, int shader_waves = 0) {
-    if (accel == 3 && !stats) {  // the 80-byte nodes are for scenes beyond the caches, which run with two shading waves
+    if (accel == 3 && !stats) {  // the same for the 80-byte nodes
+        if (!batch && shader_waves == 3) return pool_kernel<3, false, false, 3>;
         if (!batch && shader_waves == 2) return pool_kernel<3, false, false, 2>;
+        if (batch && shader_waves == 4) return pool_kernel<3, false, true, 4>;
         if (batch && shader_waves == 2) return pool_kernel<3, false, true, 2>;
     }
     if (accel == 2 && !stats) {  // the instances with the shading waves compiled in

@@ -495,13 +495,15 @@ static int pooled_bvh_width(const RtContext* c, int overflow_words) {
 // Node format of the four-wide tree for the pooled kernel.  The 80-byte nodes (binary16 boxes relative to a point of
 // the node) take five 16-byte loads per visit instead of seven and three more multiply-adds: where the tree does not
 // fit the caches the fetch path is what the vector pipes wait for (1.07 M triangles, 16 frames per launch: L1 / texture
-// path 71 % busy, 80 % of the issue slots used -> 60 % / 87 %, 9.28 -> 8.60 ms per frame; a frame alone 10.99 -> 10.55), where
-// it does fit they are pure cost (teapot scene 6.77 -> 6.88 ms, star scene 2.24 -> 2.28).  Same bits either way.
+// path 71 % busy, 80 % of the issue slots used -> 60 % / 87 %, 9.11 -> 8.44 ms per frame; a frame alone 10.96 -> 10.56), where
+// it does fit they are pure cost.  Fields of n x n teapots at 1080p (tools/field_time.py, ms per frame, 128- / 80-byte
+// nodes): 0.5 MB of scene 3.54 / 3.61, 1.9 MB 4.03 / 4.02, 4.3 MB 4.49 / 4.44, 7.7 MB 4.94 / 4.83, 12 MB 5.49 / 5.34, 17 MB 6.66 / 6.46,
+// 31 MB 7.78 / 7.45: they pay from about the size of one XCD's L2 (4 MB).  Same bits either way.
 static bool pooled_half_nodes(const RtContext* c) {
     if (!c->d_nodes_wide16) return false;
     if (c->opt.bvh_node_format != 0) return c->opt.bvh_node_format == 16;
     const size_t scene_bytes = (size_t)c->n_prims * 48u + (size_t)c->bvh_nodes * 64u;
-    return scene_bytes > ((size_t)16 << 20);
+    return scene_bytes > ((size_t)4 << 20);
 }
 // Search steps of a pooled wave between two looks at the queues: about as many as a ray takes, so that few
 // lanes sit finished through the rest of a burst.  Four-wide tree, 1080p: the small scenes' rays take 6 lane steps

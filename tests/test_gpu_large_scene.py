@@ -188,7 +188,7 @@ def test_scene_of_36_meshes_beyond_the_builders_parallel_threshold(ctx, pipeline
     g = frames_of(ctx, s, W, H, spp=1, max_bounces=4, camera=cam, flags=DEBUG_FLAGS | pipeline)
     assert_identical_but_edge_ties(g, o)
     if pipeline == capi.RT_FLAG_POOLED:
-        assert g["stats"].bvh_node_bytes == 80  # beyond 16 MB: binary16 boxes
+        assert g["stats"].bvh_node_bytes == 80  # beyond 4 MB: binary16 boxes
     seen = o["primary_ids"][o["primary_ids"] >= 4]  # ids 0-3: floor and lamp; mesh m's triangles follow at 4 + 6320 m
     assert len(np.unique((seen - 4) // 6320)) > 10  # many of the meshes are seen
     f = frames_of(ctx, s, W, H, spp=1, max_bounces=4, camera=cam, accel=capi.RT_ACCEL_FLAT)

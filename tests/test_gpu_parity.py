@@ -374,7 +374,7 @@ def test_tile_order_feedback_changes_the_schedule_only(ctx, teapot, pipeline, st
 def test_tree_widths_agree(ctx, teapot, kind, pipeline):
     """Both kernels walk the four-wide form of the tree unless told otherwise (RT_OPT_BVH_WIDTH) or its stack
     does not fit, and the pooled kernel reads it in 128-byte nodes or in 80-byte nodes with binary16 boxes
-    (RT_OPT_BVH_NODE_FORMAT; by itself only on scenes beyond 16 MB): every form holds the same leaves behind boxes that
+    (RT_OPT_BVH_NODE_FORMAT; by itself only on scenes beyond 4 MB): every form holds the same leaves behind boxes that
     contain them, so they must agree bit for bit - with each other, and (but for edge ties) with the oracle."""
     from helpers import DEBUG_FLAGS
     W, H = 120, 68
