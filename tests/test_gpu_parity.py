@@ -421,9 +421,14 @@ def test_pooled_kernel_on_trees_of_a_single_node(ctx, kind):
     assert w["nodes"] == 1 and w["stack_need"] <= 2
     W, H = 160, 120  # 19 200 pixels
     o = oracle_frames(s, W, H, spp=2, max_bounces=3)
-    g = gpu_frames(ctx, s, W, H, spp=2, max_bounces=3, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
-    assert g["stats"].pipeline == capi.RT_PIPELINE_POOLED and g["stats"].bvh_width == 4
-    assert_identical(g, o)
+    try:
+        for fmt, node_bytes in ((0, 128), (16, 80)):  # both node formats: an empty place is a negative half extent in either
+            ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, fmt)
+            g = gpu_frames(ctx, s, W, H, spp=2, max_bounces=3, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | capi.RT_FLAG_POOLED)
+            assert g["stats"].pipeline == capi.RT_PIPELINE_POOLED and g["stats"].bvh_width == 4 and g["stats"].bvh_node_bytes == node_bytes
+            assert_identical(g, o)
+    finally:
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 0)
 
 
 @pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])

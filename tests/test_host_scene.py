@@ -173,8 +173,12 @@ def test_parallel_bvh_build_lays_the_tree_out_as_the_serial_build_does(monkeypat
 
 def test_wide_tree_holds_the_binary_trees_leaves():
     """The four-wide form of the tree, which the pooled kernel walks: collapse + structural check (every leaf of
-    the binary tree exactly once, every node reachable once, stack need and depth as stored)."""
-    for preset in (capi.RT_SCENE_CORNELL_STAR, capi.RT_SCENE_CORNELL_TEAPOT, capi.RT_SCENE_PRESET1_TEAPOT):
+    the binary tree exactly once, every node reachable once, stack need and depth as stored; and for its 80-byte
+    form with binary16 boxes: the same children, every box - a point of the node + relative centre -+ half extent, as
+    real numbers - contains the 128-byte form's box, no subnormal halves, empty places not enterable)."""
+    e = Scene(capi.RT_SCENE_EMPTY)
+    assert e.wide_bvh_info()["nodes"] == 1
+    for preset in (capi.RT_SCENE_CORNELL_STAR, capi.RT_SCENE_CORNELL_TEAPOT, capi.RT_SCENE_PRESET1_TEAPOT, capi.RT_SCENE_TEAPOT_GRID):
         s = Scene(preset)
         b, w = s.bvh_info(), s.wide_bvh_info()  # raises if the structural validation fails
         assert 0 < w["nodes"] <= b["nodes"]
