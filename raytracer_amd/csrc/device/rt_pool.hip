@@ -206,28 +206,6 @@ RT_DEV void queue_push(PoolLds& L, int q, bool want, uint32_t item) {
     if (lane_id() == leader) atomicAdd(&L.hc[q], n);  // LDS operations of one wave complete in order: after the entries
 }
 
-// RT_OCTANT_ORDER (experiment, default off): the rays a shading job sends to the search queue take their ring places in
-// the order of their direction's octant instead of lane order, so that a wave refilling its idle lanes from
-// consecutive places gets rays that walk the tree the same way round.
-#ifndef RT_OCTANT_ORDER
-#define RT_OCTANT_ORDER 0
-#endif
-#if RT_OCTANT_ORDER
-RT_DEV uint32_t octant_rank(bool mine, uint32_t oct) {
-    uint32_t below = 0, rank = 0;
-#pragma unroll
-    for (uint32_t o = 0; o < 8u; ++o) {
-        const unsigned long long m = __ballot(mine && oct == o);
-        rank = (mine && oct == o) ? below + (uint32_t)__popcll(m & lanes_below()) : rank;
-        below += (uint32_t)__popcll(m);
-    }
-    return rank;
-}
-RT_DEV uint32_t slot_octant(const PoolLds& L, uint32_t i) {
-    return (__float_as_uint(L.rd[0][i]) >> 31) | ((__float_as_uint(L.rd[1][i]) >> 31) << 1) | ((__float_as_uint(L.rd[2][i]) >> 31) << 2);
-}
-#endif
-
 // The same for several queues at once: every lane names its queue (0..kQueues-1, or -1 for
 // nothing) and its item; lane k reserves for queue k, so the wave pays one LDS atomic round trip
 // however many queues receive entries.  MASK: the queues this call site can name (the others cost nothing).
@@ -257,15 +235,8 @@ RT_DEV void queue_push_any(PoolLds& L, int q, uint32_t item) {
         if (q == k) { base = pk; mk = m[k]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // before the entry store, as in queue_push
-#if RT_OCTANT_ORDER
-    uint32_t orank = 0;
-    if ((MASK >> Q_SEARCH) & 1u) orank = octant_rank(q == Q_SEARCH, q == Q_SEARCH ? slot_octant(L, item & 0xfffu) : 0u);
-#endif
     if (q >= 0) {
-        uint32_t at = base + (uint32_t)__popcll(mk & lanes_below());
-#if RT_OCTANT_ORDER
-        if (((MASK >> Q_SEARCH) & 1u) && q == Q_SEARCH) at = base + orank;
-#endif
+        const uint32_t at = base + (uint32_t)__popcll(mk & lanes_below());
         // (a call site that cannot name the search queue needs no look at which ring it is)
         const uint32_t idx = ((MASK >> Q_SEARCH) & 1u) ? ring_entry(q, at) : (uint32_t)(q + 1) * (uint32_t)kRing + (at & (uint32_t)(kRing - 1));
         *(volatile lds_u16*)&L.items[idx] = (uint16_t)item;
