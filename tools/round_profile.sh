@@ -20,7 +20,7 @@ python3 tools/pmc_summary.py $out/pmc_c3_pooled "pool_kernel<2, false, false" 1 
 BENCH_ARGS="--pipeline pooled --frames-per-launch 16" bash tools/pmc_passes.sh $out/pmc_c3_fused || exit 1
 python3 tools/pmc_summary.py $out/pmc_c3_fused "pool_kernel<2, false, true" 1 > $out/c3_pooled_fused16_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline pooled --frames-per-launch 1" bash tools/pmc_passes.sh $out/pmc_c5_pooled || exit 1
-python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<2, false, false" 1 > $out/c5_pooled_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c5_pooled "pool_kernel<3, false, false" 1 > $out/c5_pooled_pmc.txt
 BENCH_ARGS="--workload c5 --pipeline pooled --frames-per-launch 16" bash tools/pmc_passes.sh $out/pmc_c5_fused || exit 1
-python3 tools/pmc_summary.py $out/pmc_c5_fused "pool_kernel<2, false, true" 1 > $out/c5_pooled_fused16_pmc.txt
+python3 tools/pmc_summary.py $out/pmc_c5_fused "pool_kernel<3, false, true" 1 > $out/c5_pooled_fused16_pmc.txt
 cat $out/bench_c3.json; head -4 $out/c3_kernel_stats.csv | cut -c1-160
