@@ -558,30 +558,35 @@ def test_shading_waves_change_the_schedule_only(ctx, teapot):
         ctx.set_option(capi.RT_OPT_POOL_JOB_MIN, 0)
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_benchmark_sampling_against_the_oracle(ctx, teapot, fused):
-    """The benchmark's scene, camera and sampling (C3: Cornell box + teapot.glb, 16 spp, 4 bounces, still camera, two
-    accumulated frames) at an eighth of its width and height, where the oracle's flat loops finish in seconds: the
-    library's own choice of kernel, frame by frame and as one fused launch, against the oracle - accumulated floats,
-    counts, BGRA8 bytes (and the ray count where no pixel is an edge tie)."""
-    from raytracer_amd.workloads import WORKLOADS
-    _, _, _, spp, mb, _ = WORKLOADS["c3"]
-    W, H, n = 240, 135, 2
-    o = oracle_frames(teapot, W, H, spp=spp, max_bounces=mb, frames=n, threads=16)
-    ctx.upload_scene(teapot)
+@pytest.mark.parametrize("workload,W,H,fused", [("c3", 240, 135, False), ("c3", 240, 135, True), ("c2", 240, 135, True), ("c4", 240, 135, False),
+                                                ("c5", 32, 18, False)])
+def test_benchmark_sampling_against_the_oracle(ctx, workload, W, H, fused):
+    """Every benchmark configuration's own scene, camera and sampling (C3: Cornell box + teapot.glb, 16 spp x 4 bounces;
+    C2: the reference's default scene, 4 spp x 20 bounces; C4: the teapot scene, 4 spp x 20 bounces; C5: 1.07 M triangles,
+    8 spp x 20 bounces), two accumulated frames of the still camera, at a size where the oracle's flat loops finish in
+    seconds: the pooled kernel - frame by frame, or as one fused launch where the image has enough tiles for one -
+    against the oracle: accumulated floats, counts, BGRA8 bytes (and the ray count where no pixel is an edge tie)."""
+    from raytracer_amd.workloads import WORKLOADS, workload_camera
+    preset, _, _, spp, mb, _ = WORKLOADS[workload]
+    s = Scene(preset)
+    n = 2
+    cam = workload_camera(workload, W, H)
+    o = oracle_frames(s, W, H, spp=spp, max_bounces=mb, frames=n, camera=cam, threads=16)
+    ctx.upload_scene(s)
     ctx.resize(W, H)
-    cam = default_camera(W, H)
-    pcs = [teapot.push_constants(0.0, f, f == 0) for f in range(n)]
+    pcs = [s.push_constants(0.0, f, f == 0) for f in range(n)]
+    params = make_params(spp, mb, capi.RT_ACCEL_BVH, 0, 1, 0, capi.RT_FLAG_POOLED)
     rays = 0
     if fused:
-        ctx.render_frames(cam, pcs, make_params(spp, mb, capi.RT_ACCEL_BVH))
+        ctx.render_frames(cam, pcs, params)
         assert ctx.stats().frames == n
         rays = ctx.stats().rays
     else:
         for pc in pcs:
-            ctx.render_frame(cam, pc, make_params(spp, mb, capi.RT_ACCEL_BVH))
+            ctx.render_frame(cam, pc, params)
             rays += ctx.stats().rays
-    assert ctx.stats().pipeline == capi.RT_PIPELINE_POOLED and ctx.stats().bvh_width == 4
+    st = ctx.stats()
+    assert st.pipeline == capi.RT_PIPELINE_POOLED and st.bvh_width == 4 and st.bvh_node_bytes == (80 if workload == "c5" else 128)
     acc, cnt = ctx.read_accum()
     same = bit_equal_pixels(acc, o["accum"])
     assert (~same).sum() <= 3, f"{(~same).sum()} of {same.size} pixels differ from the oracle"
