@@ -118,6 +118,9 @@ RT_DEV void cold_store(float4* p, float4 v) {
 #endif
 }
 
+// Slot i's cold record in the workgroup's region (a 32-bit offset from a uniform base: see table_row).
+RT_DEV float4* cold_of(float4* base, uint32_t i) { return (float4*)((char*)base + i * 64u); }
+
 // Accessor of slot i: hot fields in LDS, cold record (pixel sum, pixel cost | the light's term: normal,
 // light distance | incoming direction, packed bits | light direction, hit id; 64 bytes) in device memory.
 struct PoolSlot {
@@ -327,7 +330,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
                 uint32_t frame, block;
                 bool exhausted;
                 if (batch_slot_to_pixel(fa, xcd, mine, x, y, frame, block, exhausted)) {
-                    start_pixel<BATCH>(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y, frame);
+                    start_pixel<BATCH>(fa, PoolSlot{L, cold_of(cold_base, local), local}, x, y, frame);
                     need = false;
                     started = true;
                 } else if (exhausted) {
@@ -339,7 +342,7 @@ RT_DEV bool take_pixels(PoolLds& L, const FrameArgs& fa_hot, float4* cold_base, 
                 need = false;
                 dead = true;
             } else if (slot_to_pixel(fa, mine, x, y)) {
-                start_pixel<BATCH>(fa, PoolSlot{L, cold_base + 4 * local, local}, x, y);
+                start_pixel<BATCH>(fa, PoolSlot{L, cold_of(cold_base, local), local}, x, y);
                 need = false;
                 started = true;
             }
@@ -459,7 +462,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
             const int jk = q == Q_FIRST ? 0 : q == Q_NEXT ? 1 : q == Q_LIT ? 2 : 3;  // STATS index: first-bounce, later-bounce, light's term, sample / pixel end / misses
             if (STATS) job_stats[jk] += ((unsigned long long)n_items << 32) | 1ull;
             const uint32_t i = item & 0xfffu;
-            const PoolSlot ps{L, cold_base + 4 * i, i};
+            const PoolSlot ps{L, cold_of(cold_base, i), i};
             if (q == Q_PIXEL) {
                 // (in a launch of several frames a pixel may have to wait for its previous frame's store: back into the queue)
                 const bool ended = got && end_pixel_item<BATCH>(fa, ps);
@@ -531,14 +534,14 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                 entry = (uint32_t)slot | (tv.best_idx < 0 ? (uint32_t)skind << 12 : 0u);
             }
             if (hash_mode && mine && skind >= 2)  // the query's hit id, for the per-pixel hash
-                ((int*)(cold_base + 4 * slot + 3))[3] = tv.best_idx >= 0 ? __float_as_int(recs[3 * tv.best_idx].w) : -1;
+                ((int*)(cold_of(cold_base, (uint32_t)slot) + 3))[3] = tv.best_idx >= 0 ? __float_as_int(table_row(recs, tv.best_idx, 48u)[0].w) : -1;
             if (hash_mode) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (mine && skind >= 2) {
                 // a light query: the light is visible if the nearest hit lies within 0.1 of the sampled point
                 // (raytracer.comp:617-626, 662-671), a directional one if nothing is hit (636-644).  The
                 // sample's end is queued by whichever of query and path finishes last.
                 const bool visible = skind == 3 ? tv.best_idx < 0 : (tv.best_idx >= 0 && g_abs(s_d - tv.best_t) < 0.1f);
-                const PoolSlot ps{L, cold_base + 4 * slot, (uint32_t)slot};
+                const PoolSlot ps{L, cold_of(cold_base, (uint32_t)slot), (uint32_t)slot};
                 if (ps.or_flags(LF_DONE | (visible ? LF_LIT : 0u)) & LF_PATH_DONE) to = end_queue(ps, visible ? LF_LIT : 0u);
             }
             queue_push_any<(1u << Q_FIRST) | (1u << Q_NEXT) | (1u << Q_MISS) | (1u << Q_END) | (1u << Q_LIT) | (1u << Q_PIXEL)>(L, to, entry);
@@ -565,7 +568,7 @@ __global__ void __launch_bounds__(kThreads, RT_POOL_WAVES_PER_SIMD) pool_kernel(
                     s_d = skind == 3 ? kInf : length(to_light);
                     rd = skind == 3 ? to_light : normalize(to_light);
                     L.col[0][slot] = 0.0f; L.col[1][slot] = 0.0f; L.col[2][slot] = 0.0f;  // the sample's radiance again
-                    (void)PoolSlot{L, cold_base + 4 * slot, (uint32_t)slot}.or_flags(LF_FETCHED);
+                    (void)PoolSlot{L, cold_of(cold_base, (uint32_t)slot), (uint32_t)slot}.or_flags(LF_FETCHED);
                 }
                 n_rays++;
                 if (ACCEL >= 1) {

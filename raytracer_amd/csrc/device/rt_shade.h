@@ -49,8 +49,15 @@ struct Hit {  // raytracer.comp:108-114
     bool front_face;
 };
 
+// Row `index` of a table of `row_bytes`-byte rows: the offset is formed in 32 bits, so that a load from a uniform base
+// compiles to base-in-scalar-registers + one 32-bit lane offset instead of 64-bit vector address arithmetic (every table
+// the kernels index - records, nodes, materials, lights, triangles - is below 4 GB: the host refuses larger scenes).
+RT_DEV const float4* table_row(const float4* __restrict__ base, int index, uint32_t row_bytes) {
+    return (const float4*)((const char*)base + (uint32_t)index * row_bytes);
+}
+
 RT_DEV Material load_material(const float4* __restrict__ mats, int idx) {
-    const float4* m = mats + 5 * idx;
+    const float4* m = table_row(mats, idx, 80u);
     float4 a = m[0], s = m[1], sp = m[2], e = m[3], g = m[4];
     Material r;
     r.albedo = v3(a.x, a.y, a.z);         r.albedo_a = a.w;

@@ -107,7 +107,7 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
                     sl.put_light_record(q);
                     if (k == 0) {  // visibility to be searched
                         sl.put_col(to_light);  // the query's ray, until a lane has taken it
-                        light_kind = (__float_as_int(sc.lights[3 * q.light + 2].x) == 3 /* DIRECTIONAL */) ? 3 : 2;
+                        light_kind = (__float_as_int(table_row(sc.lights, q.light, 48u)[2].x) == 3 /* DIRECTIONAL */) ? 3 : 2;
                         flags = LF_PENDING;
                     } else {  // no search: AMBIENT (not shadow-tested) and the shader's undefined light types count as lit
                         flags = LF_PENDING | LF_FETCHED | LF_DONE | LF_LIT | LF_FOLDED;
@@ -149,8 +149,8 @@ RT_DEV V3 lit_term(const DeviceScene& sc, const Slot& sl) {
     Hit h;
     h.p = v3(0.0f); h.t = 0.0f;
     h.normal = q.normal; h.mat = q.mat; h.front_face = q.front_face;
-    const float4 lc = sc.lights[3 * q.light + 1];
-    const int ltype = __float_as_int(sc.lights[3 * q.light + 2].x);
+    const float4 lc = table_row(sc.lights, q.light, 48u)[1];
+    const int ltype = __float_as_int(table_row(sc.lights, q.light, 48u)[2].x);
     V3 Le;
     float light_pdf;
     if (ltype == 3 /* DIRECTIONAL */) {

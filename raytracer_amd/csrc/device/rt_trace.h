@@ -53,7 +53,8 @@ RT_DEV void intersect_loaded(float4 A, float4 B, float4 C, int idx, V3 ro, V3 rd
 }
 RT_DEV void intersect_record(const float4* __restrict__ recs, int idx, V3 ro, V3 rd, float& best_t, int& best_prio,
                              int& best_idx) {
-    intersect_loaded(recs[3 * idx + 0], recs[3 * idx + 1], recs[3 * idx + 2], idx, ro, rd, best_t, best_prio, best_idx);
+    const float4* __restrict__ r = table_row(recs, idx, 48u);
+    intersect_loaded(r[0], r[1], r[2], idx, ro, rd, best_t, best_prio, best_idx);
 }
 
 // The reference's search: every primitive, in the order of its three loops.
@@ -148,10 +149,11 @@ RT_DEV Slab make_slab(V3 ro, V3 rd) {
 // nearer hit child, push the other.
 template <typename Stack>
 RT_DEV void trav_node_step(const float4* __restrict__ nodes, const Slab& sl, const Stack& stack, Trav& tv) {
-    const float4 q0 = nodes[4 * tv.cur + 0];
-    const float4 q1 = nodes[4 * tv.cur + 1];
-    const float4 q2 = nodes[4 * tv.cur + 2];
-    const float4 q3 = nodes[4 * tv.cur + 3];
+    const float4* __restrict__ nd = table_row(nodes, tv.cur, 64u);
+    const float4 q0 = nd[0];
+    const float4 q1 = nd[1];
+    const float4 q2 = nd[2];
+    const float4 q3 = nd[3];
     // child 0: lo (q0.x q0.y q0.z) hi (q0.w q1.x q1.y); child 1: lo (q1.z q1.w q2.x) hi (q2.y q2.z q2.w)
     float a0 = __builtin_fmaf(q0.x, sl.ix, sl.ox), b0 = __builtin_fmaf(q0.w, sl.ix, sl.ox);
     float a1 = __builtin_fmaf(q0.y, sl.iy, sl.oy), b1 = __builtin_fmaf(q1.x, sl.iy, sl.oy);
@@ -202,7 +204,7 @@ RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, con
     float4 w;
     float ox, oy, oz;  // the slab offsets the centres are taken against
     if (HALF) {
-        const float4* __restrict__ nd = nodes + 5 * (size_t)tv.cur;
+        const float4* __restrict__ nd = table_row(nodes, tv.cur, 80u);
         const float4 org = nd[0], qa = nd[1], qb = nd[2], qc = nd[3];
         w = nd[4];
         ox = __builtin_fmaf(org.x, sl.ix, sl.ox); oy = __builtin_fmaf(org.y, sl.iy, sl.oy); oz = __builtin_fmaf(org.z, sl.iz, sl.oz);
@@ -213,7 +215,7 @@ RT_DEV void trav_wide_step(const float4* __restrict__ nodes, const Slab& sl, con
         hy = {half_lo(qc.x), half_hi(qc.x), half_lo(qc.y), half_hi(qc.y)};
         hz = {half_lo(qc.z), half_hi(qc.z), half_lo(qc.w), half_hi(qc.w)};
     } else {
-        const float4* __restrict__ nd = nodes + 8 * (size_t)tv.cur;
+        const float4* __restrict__ nd = table_row(nodes, tv.cur, 128u);
         const float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3], e = nd[4], f = nd[5];
         w = nd[6];
         cx = {a.x, a.y, a.z, a.w}; cy = {b.x, b.y, b.z, b.w}; cz = {c.x, c.y, c.z, c.w};
@@ -276,8 +278,10 @@ RT_DEV void trav_leaf_step2(const float4* __restrict__ prims, V3 ro, V3 rd, cons
     const int first = tv.cur & 0x0fffffff;
     const int left = (tv.cur >> 28) & 7;  // primitives after this one
     const int second = first + (left > 0 ? 1 : 0);
-    const float4 A0 = prims[3 * first + 0], B0 = prims[3 * first + 1], C0 = prims[3 * first + 2];
-    const float4 A1 = prims[3 * second + 0], B1 = prims[3 * second + 1], C1 = prims[3 * second + 2];
+    const float4* __restrict__ r0 = table_row(prims, first, 48u);
+    const float4* __restrict__ r1 = table_row(prims, second, 48u);
+    const float4 A0 = r0[0], B0 = r0[1], C0 = r0[2];
+    const float4 A1 = r1[0], B1 = r1[1], C1 = r1[2];
     intersect_loaded(A0, B0, C0, first, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
     if (left > 0) intersect_loaded(A1, B1, C1, second, ro, rd, tv.best_t, tv.best_prio, tv.best_idx);
     if (left <= 1) trav_pop(tv, stack);
@@ -287,9 +291,10 @@ RT_DEV void trav_leaf_step2(const float4* __restrict__ prims, V3 ro, V3 rd, cons
 // Hit record of the winning primitive (raytracer.comp:354-358, 398-403, 454-461).
 RT_DEV void make_hit(const DeviceScene& sc, const float4* __restrict__ recs, int idx, float t, V3 ro, V3 rd, Hit& h,
                      int& prim_id) {
-    const float4 A = recs[3 * idx + 0];
-    const float4 B = recs[3 * idx + 1];
-    const float4 C = recs[3 * idx + 2];
+    const float4* __restrict__ r = table_row(recs, idx, 48u);
+    const float4 A = r[0];
+    const float4 B = r[1];
+    const float4 C = r[2];
     prim_id = __float_as_int(A.w);
     const int matbits = __float_as_int(C.w);
     h.t = t;
@@ -301,7 +306,7 @@ RT_DEV void make_hit(const DeviceScene& sc, const float4* __restrict__ recs, int
     } else {
         h.mat = matbits;
         if (prim_id < sc.n_spheres + sc.n_triangles) {
-            const float4 n = sc.triangles[4 * (prim_id - sc.n_spheres) + 3];  // stored Triangle.normal
+            const float4 n = table_row(sc.triangles, prim_id - sc.n_spheres, 64u)[3];  // stored Triangle.normal
             outward = v3(n.x, n.y, n.z);
         } else {
             outward = normalize(cross(v3(B.x, B.y, B.z), v3(C.x, C.y, C.z)));
@@ -503,11 +508,11 @@ RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, 
     int low = 0, high = fa.total_lights - 1;
     while (low < high) {
         int mid = (low + high) / 2;
-        if (rand_strength <= sc.lights[3 * mid + 2].y) high = mid; else low = mid + 1;
+        if (rand_strength <= table_row(sc.lights, mid, 48u)[2].y) high = mid; else low = mid + 1;
     }
     light = low;
-    const float4 lp = sc.lights[3 * low + 0];
-    const int ltype = __float_as_int(sc.lights[3 * low + 2].x);
+    const float4 lp = table_row(sc.lights, low, 48u)[0];
+    const int ltype = __float_as_int(table_row(sc.lights, low, 48u)[2].x);
     s_d = 0.0f;
     s_L = v3(0.0f);
     to_light = v3(0.0f);
@@ -536,9 +541,10 @@ RT_DEV int light_pick(const DeviceScene& sc, const FrameArgs& fa, const Hit& h, 
     }
     if (ltype == 6 /* TRIANGLE */) {
         const int ti = (int)lp.x;
-        const float4 t0 = sc.triangles[4 * ti + 0];
-        const float4 t1 = sc.triangles[4 * ti + 1];
-        const float4 t2 = sc.triangles[4 * ti + 2];
+        const float4* __restrict__ tri = table_row(sc.triangles, ti, 64u);
+        const float4 t0 = tri[0];
+        const float4 t1 = tri[1];
+        const float4 t2 = tri[2];
         float e1 = g_sqrt(rng_random(seed));
         float e2 = rng_random(seed);
         V3 tri_point = (1.0f - e1) * v3(t0.x, t0.y, t0.z) + e1 * (1.0f - e2) * v3(t1.x, t1.y, t1.z) + e1 * e2 * v3(t2.x, t2.y, t2.z);

@@ -186,7 +186,9 @@ int build_scene(const RtOptions& opt, const RtSphere* spheres, int32_t n_spheres
     a.indices = indices;     a.n_indices = n_indices;
     a.meshes = meshes;       a.n_meshes = n_meshes;
     if (!rt::gather_primitives(a, out.flat, &err)) return RT_ERR_INVALID_ARGUMENT;
-    if (out.flat.size() >= (size_t)(1u << 28)) { err = "more than 2^28 primitives"; return RT_ERR_TOO_LARGE; }
+    // (the kernels address records and nodes by 32-bit byte offsets: 2^26 records of 48 bytes are 3.2 GB, and their
+    // tree's nodes - at most a third as many four-wide nodes of 128 bytes, as many binary ones of 64 - stay below 4 GB too)
+    if (out.flat.size() >= (size_t)(1u << 26)) { err = "more than 2^26 primitives"; return RT_ERR_TOO_LARGE; }
     if (!rt::build_bvh(a, out.bvh, &err, opt.bvh_max_leaf)) return RT_ERR_INVALID_ARGUMENT;
     if (out.bvh.depth > rt::kMaxBvhDepth || out.bvh.max_leaf > 8) { err = "BVH exceeds traversal limits"; return RT_ERR_TOO_LARGE; }
     rt::layout_treelets(out.bvh, opt.bvh_treelet);
