@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
             // per-pixel hash of nearest-hit ids is recorded, which needs the true nearest hit.
             t_occl = -kInf;
             if (ACCEL >= 1 && state == ST_TRACE_LIGHT && !(fa.flags & 2u)) {
-                if (__float_as_int(sc.lights[3 * s_light + 2].x) == 3 /* DIRECTIONAL */) {
+                if (__float_as_int(table_row(sc.lights, s_light, 48u)[2].x) == 3 /* DIRECTIONAL */) {
                     t_occl = kInf;
                 } else {
                     t_occl = s_d - 0.2f;
@@ -223,9 +223,9 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
 
         if (ready && state == ST_TRACE_LIGHT) {
             // second half of sample_light (raytracer.comp:617-626, 636-644, 662-671)
-            if (hit_idx >= 0) prim_id = __float_as_int(recs[3 * hit_idx].w);
-            const float4 lc = sc.lights[3 * s_light + 1];
-            const int ltype = __float_as_int(sc.lights[3 * s_light + 2].x);
+            if (hit_idx >= 0) prim_id = __float_as_int(table_row(recs, hit_idx, 48u)[0].w);
+            const float4 lc = table_row(sc.lights, s_light, 48u)[1];
+            const int ltype = __float_as_int(table_row(sc.lights, s_light, 48u)[2].x);
             Ldir = sh.normal;
             light_pdf = 0.00001f;
             if (ltype == 3 /* DIRECTIONAL */) {
@@ -266,11 +266,11 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                         int low = 0, high = fa.total_lights - 1;
                         while (low < high) {
                             int mid = (low + high) / 2;
-                            if (rand_strength <= sc.lights[3 * mid + 2].y) high = mid; else low = mid + 1;
+                            if (rand_strength <= table_row(sc.lights, mid, 48u)[2].y) high = mid; else low = mid + 1;
                         }
-                        const float4 lp = sc.lights[3 * low + 0];
-                        const float4 lc = sc.lights[3 * low + 1];
-                        const int ltype = __float_as_int(sc.lights[3 * low + 2].x);
+                        const float4 lp = table_row(sc.lights, low, 48u)[0];
+                        const float4 lc = table_row(sc.lights, low, 48u)[1];
+                        const int ltype = __float_as_int(table_row(sc.lights, low, 48u)[2].x);
                         bool search = false;
                         if (ltype == 0 /* AMBIENT */) {
                             Ldir = random_vec_on_hemisphere(h.normal, seed);
@@ -296,9 +296,9 @@ __global__ void __launch_bounds__(kBlock, 4) render_kernel(const DeviceScene sc,
                             }
                         } else if (ltype == 6 /* TRIANGLE */) {
                             const int ti = (int)lp.x;
-                            const float4 t0 = sc.triangles[4 * ti + 0];
-                            const float4 t1 = sc.triangles[4 * ti + 1];
-                            const float4 t2 = sc.triangles[4 * ti + 2];
+                            const float4 t0 = table_row(sc.triangles, ti, 64u)[0];
+                            const float4 t1 = table_row(sc.triangles, ti, 64u)[1];
+                            const float4 t2 = table_row(sc.triangles, ti, 64u)[2];
                             float e1 = g_sqrt(rng_random(seed));
                             float e2 = rng_random(seed);
                             V3 tri_point = (1.0f - e1) * v3(t0.x, t0.y, t0.z) + e1 * (1.0f - e2) * v3(t1.x, t1.y, t1.z) +
