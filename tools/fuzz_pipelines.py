@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random small configurations (size, samples, bounces, strips, skybox, scene, frames) rendered by the
-single kernel on the binary tree (the reference run), and by the single kernel, the pooled kernel and the
-library's own choice on the four-wide tree; all outputs must be bit-identical, and the flat-search run must
+single kernel on the binary tree (the reference run), and by the single kernel, the pooled kernel (128-byte and
+80-byte nodes) and the library's own choice on the four-wide tree; all outputs must be bit-identical, and the flat-search run must
 match the CPU oracle.  Scenes: the presets and random heaps of spheres and triangles with a light or two.
     python tools/fuzz_pipelines.py [cases] [seed]"""
 import os, random, sys
@@ -51,8 +51,13 @@ for k in range(cases):
     ctx.set_option(capi.RT_OPT_BVH_WIDTH, 0)
     ok = ref["stats"].bvh_width == 2 or ref["total_rays"] == 0  # (a rank that owns no rows launches nothing)
     for label, fl in (("single, wide", capi.RT_FLAG_SINGLE_KERNEL), ("pooled", capi.RT_FLAG_POOLED), ("auto", 0),
-                      ("pooled, image order", capi.RT_FLAG_POOLED | capi.RT_FLAG_FIXED_TILE_ORDER)):
+                      ("pooled, image order", capi.RT_FLAG_POOLED | capi.RT_FLAG_FIXED_TILE_ORDER), ("pooled, 80-byte nodes", capi.RT_FLAG_POOLED)):
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 16 if "80-byte" in label else 0)
         g = gpu_frames(ctx, s, W, H, accel=capi.RT_ACCEL_BVH, flags=DEBUG_FLAGS | fl, **kw)
+        ctx.set_option(capi.RT_OPT_BVH_NODE_FORMAT, 0)
+        if "80-byte" in label and g["total_rays"] != 0 and g["stats"].bvh_node_bytes != 80:
+            ok = False
+            print("  the 80-byte nodes were not used")
         same = (bit_equal_pixels(g["accum"], ref["accum"]).all() and np.array_equal(g["counts"], ref["counts"]) and
                 np.array_equal(g["bgra"], ref["bgra"]) and np.array_equal(g["path_hash"], ref["path_hash"]) and
                 g["total_rays"] == ref["total_rays"])
