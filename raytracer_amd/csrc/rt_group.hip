@@ -198,7 +198,9 @@ int gfail(RtGroup* g, int code, const std::string& msg) {
 void free_group_buffers(RtGroup* g) {
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         (void)hipSetDevice(g->ctx[i]->device);
+        // both streams touch the buffers: the exchange writes them, the context's unpack and pack read and write them
         if (i < g->xfer.size() && g->xfer[i]) (void)hipStreamSynchronize(g->xfer[i]);
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
         if (i < g->staging.size() && g->staging[i]) (void)hipFree(g->staging[i]);
         if (i < g->gathered.size() && g->gathered[i]) (void)hipFree(g->gathered[i]);
     }
