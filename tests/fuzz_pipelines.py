@@ -3,10 +3,10 @@
 single kernel on the binary tree (the reference run), and by the single kernel, the pooled kernel (128-byte and
 80-byte nodes) and the library's own choice on the four-wide tree; all outputs must be bit-identical, and the flat-search run must
 match the CPU oracle.  Scenes: the presets and random heaps of spheres and triangles with a light or two.
-    python tools/fuzz_pipelines.py [cases] [seed]"""
+    python tests/fuzz_pipelines.py [cases] [seed]      (a checker, not collected by pytest: it runs as long as it is told to)"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # helpers.py lives beside this file
 import numpy as np
 from helpers import DEBUG_FLAGS, bit_equal_pixels, gpu_frames, oracle_frames
 from raytracer_amd import capi
