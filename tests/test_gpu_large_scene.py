@@ -1,5 +1,5 @@
 """GPU parity of what only scenes beyond 65 536 primitives exercise: the host builder's thread-pool path, the
-four-wide collapse of a deep tree (its traversal can hold 43 stack entries on the 1.07 M-triangle scene), the
+four-wide collapse of a deep tree (its traversal can hold 44 stack entries on the 1.07 M-triangle scene), the
 traversal stack's overflow into device memory (the pooled kernel keeps 8 entries per lane in LDS) and the launch
 heuristics that switch at 16 MB of scene.  The 1.07 M-triangle teapot grid and a 36-teapot scene of 227 524
 triangles (36 meshes with rebased indices) are compared with the CPU oracle's flat loops (raytracer.comp:408-508:

@@ -70,7 +70,7 @@ def test_noalloc_equals_render_frame_on_two_calls_the_second_smaller(flags):
 
 
 def test_noalloc_on_a_scene_whose_wide_tree_outgrows_the_scratch_stack_area():
-    """The 1.07 M-triangle scene's four-wide tree can hold 43 traversal stack entries, the scratch array has room for 31
+    """The 1.07 M-triangle scene's four-wide tree can hold 44 traversal stack entries, the scratch array has room for 31
     per lane: the no-allocation call walks the binary tree instead, rt_render_frame the wide one, and both must give
     the same frame."""
     from raytracer_amd.workloads import WORKLOADS, workload_camera

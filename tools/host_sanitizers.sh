@@ -10,10 +10,10 @@ big_scene='from raytracer_amd import capi
 from raytracer_amd.renderer import Scene
 s = Scene(capi.RT_SCENE_TEAPOT_GRID); print(s.bvh_info(), s.wide_bvh_info(), hex(s.bvh_hash()))'
 make -C raytracer_amd/csrc -j8 LIBNAME=libraytracer_amd_asan.so OBJDIR=build_asan CXXFLAGS="$FLAGS -fsanitize=address,undefined" > /dev/null
-LD_PRELOAD="$(GCCLIB libasan.so) $(GCCLIB libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+LD_PRELOAD="$(GCCLIB libasan.so) $(GCCLIB libubsan.so) $LD_PRELOAD" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
   RT_LIB_PATH=$PWD/raytracer_amd/lib/libraytracer_amd_asan.so python -m pytest tests -x -q -m "not gpu"
-LD_PRELOAD="$(GCCLIB libasan.so) $(GCCLIB libubsan.so)" ASAN_OPTIONS=detect_leaks=0 RT_LIB_PATH=$PWD/raytracer_amd/lib/libraytracer_amd_asan.so python -c "$big_scene"
+LD_PRELOAD="$(GCCLIB libasan.so) $(GCCLIB libubsan.so) $LD_PRELOAD" ASAN_OPTIONS=detect_leaks=0 RT_LIB_PATH=$PWD/raytracer_amd/lib/libraytracer_amd_asan.so python -c "$big_scene"
 make -C raytracer_amd/csrc -j8 LIBNAME=libraytracer_amd_tsan.so OBJDIR=build_tsan CXXFLAGS="$FLAGS -fsanitize=thread" > /dev/null
-LD_PRELOAD="$(GCCLIB libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0" RT_LIB_PATH=$PWD/raytracer_amd/lib/libraytracer_amd_tsan.so python -c "$big_scene"
+LD_PRELOAD="$(GCCLIB libtsan.so) $LD_PRELOAD" TSAN_OPTIONS="report_signal_unsafe=0" RT_LIB_PATH=$PWD/raytracer_amd/lib/libraytracer_amd_tsan.so python -c "$big_scene"
 rm -rf raytracer_amd/csrc/build_asan raytracer_amd/csrc/build_tsan raytracer_amd/lib/libraytracer_amd_asan.so raytracer_amd/lib/libraytracer_amd_tsan.so
 echo "host sanitizers: clean"
