@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = --frames-per-launch frames (16 unless told otherwise; a frame = one execution of the reference
+One step = --frames-per-launch frames (32 unless told otherwise; a frame = one execution of the reference
 shader's main() per pixel) of the workload BASELINE.json's metric is quoted on: Cornell box + teapot.glb,
 1920x1080, 16 samples per pixel, 4 bounces, still camera, frameCount advancing from frame to frame as in the
 reference's frame loop.  The frames of a step are handed to the library in one rt_render_frames call, which
@@ -129,9 +129,9 @@ def main() -> None:
     ap.add_argument("--pipeline", default="auto", choices=["auto", "single", "pooled"],
                     help="schedule of the per-path program (same results): the library's own choice, the single "
                          "persistent kernel, or the pooled kernel (LDS queues)")
-    ap.add_argument("--frames-per-launch", type=int, default=16,
+    ap.add_argument("--frames-per-launch", type=int, default=32,
                     help="row-strip / single-GPU runs: frames of the still camera handed to the library per step (rt_render_frames "
-                         "fuses up to 16 into one launch; with several ranks the strips are exchanged once per step); "
+                         "fuses up to 32 into one launch; with several ranks the strips are exchanged once per step); "
                          "1 = one rt_render_frame call (and one exchange) per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",

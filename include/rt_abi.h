@@ -185,7 +185,7 @@ typedef struct RtStats {
                                search steps (the rest: handing results in, taking new rays)                      */
     int32_t  bvh_width;     /* children per node of the tree the last frame's kernel walked: 2, or 4 (pooled pipeline,
                                RT_OPT_BVH_WIDTH; nodes_visited then counts four-wide nodes); 0 for the flat loops   */
-    int32_t  frames;        /* frames the last launch rendered (rt_render_frames fuses up to 16; else 1); rays, the
+    int32_t  frames;        /* frames the last launch rendered (rt_render_frames fuses up to 32; else 1); rays, the
                                traversal counts and kernel_ms are that launch's                                    */
     int32_t  search_queue_peak; /* pooled pipeline with TRAVERSAL_STATS: the most rays any workgroup's waves saw waiting
                                    for a lane at once ...                                                            */
@@ -228,7 +228,8 @@ int rt_upload_scene(RtContext* ctx,
 
 /* Replaces createImageBuffer + createFrameAccumulationBuffers and their re-creation on
  * resize (main.cpp:1501-1552, 1596-1606, 1396-1420): allocates ZEROED accumulation
- * (float4 per pixel), sample-count (int32 per pixel) and BGRA8 output buffers. */
+ * (float4 per pixel), sample-count (int32 per pixel) and BGRA8 output buffers.  An image holds at most 2^27 pixels
+ * (RT_ERR_INVALID_ARGUMENT beyond; the same bound applies to rt_bind_framebuffer and rt_render_frame_noalloc). */
 int rt_resize(RtContext* ctx, int32_t width, int32_t height);
 
 /* Same role as rt_resize but the caller provides (and keeps owning) the device memory,
@@ -250,7 +251,7 @@ int rt_render_frame(RtContext* ctx, const RtCamera* camera, const RtPushConstant
 /* n_frames consecutive rt_render_frame calls with one camera and pcs[0 .. n_frames - 1], with the same result bit for
  * bit - the reference's frame loop with a still camera (main.cpp:2160-2171: frameCount differs from frame to frame,
  * the accumulation is reset at most by the first).  Where the frames differ in frameCount only and the pooled kernel
- * applies (BVH search, no debug outputs, an image of 64 tiles to 4 M pixels), up to 16 frames at a time share ONE launch:
+ * applies (BVH search, no debug outputs, an image of 64 tiles to 4 M pixels), up to 32 frames at a time share ONE launch:
  * a pixel's frames follow each other on one XCD, so the drain of one frame's last paths is hidden behind the next
  * frame's first.  Otherwise the frames are rendered one by one.  RtStats then describe the last launch (rays: all its
  * frames). */

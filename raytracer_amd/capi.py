@@ -8,7 +8,9 @@ missing, loading raises.  The library is built by ``raytracer_amd/csrc/Makefile`
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_LIB_PATH: load another build of the same ABI (A/B timing of two builds on one device)
@@ -222,6 +224,25 @@ PROTOTYPES = {
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """A process can drive the GPU through ONE HIP runtime.  PyTorch's wheel carries its own copy (torch/lib/libamdhip64.so,
+    asked for by that file name), this library asks for the system's by its soname (libamdhip64.so.7): whichever is loaded
+    first serves the other only if it was torch's, because torch's request does not match the system copy's name - and a
+    second runtime in the process finds no GPU ("No HIP GPUs are available").  So where torch is installed but not
+    imported yet, its copy is loaded first; bench.py and parallel.py, which use both, then work in either import order."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load libraytracer_amd.so (once) and attach prototypes.  Raises if it is not built."""
     global _lib
@@ -231,6 +252,7 @@ def load() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     older_build = "RT_LIB_PATH" in os.environ  # an A/B build of another revision (tools/ab_build.sh) may lack newer entry points
     for name, (res, args) in PROTOTYPES.items():

@@ -72,11 +72,11 @@ struct FrameArgs {
     // (a frame's pixel ends after all the block's pixels of the frame before).  Both zeroed before the launch.
     int32_t n_frames;
     int32_t n_xcds;  // XCDs the launch's workgroups are spread over (their XCC_ID = 0 .. n_xcds - 1), <= kXcds
-    uint32_t frame_counts[16];
+    uint32_t frame_counts[32];
     uint32_t* xcd_next;
     uint32_t* block_done;
 };
-enum { kMaxBatchFrames = 16, kXcds = 8 };
+enum { kMaxBatchFrames = 32, kXcds = 8 };
 
 enum { kBlock = 256, kStackDepth = 32 };
 // Pixels are handed out in blocks of (1 << kBlockTilesLog2)^2 tiles of 8x8 pixels; the block is

@@ -17,7 +17,8 @@ RT_DEV float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 // that handles the first hit picks the light, notes what the term needs, sends off the visibility ray
 // and the bounce ray together, and the sample's end evaluates the term if the light proved visible.
 // Per-slot flag bits:
-enum : uint32_t { kPixelFrameShift = 28, kPixelIndexMask = (1u << 28) - 1u };  // a slot's pixel word: index | frame of the launch << 28
+enum : uint32_t { kPixelFrameShift = 27, kPixelIndexMask = (1u << 27) - 1u };  // a slot's pixel word: index | frame of the launch << 27
+static_assert(kMaxBatchFrames <= (1 << (32 - kPixelFrameShift)), "the frame of a launch must fit the pixel word's top bits");
 enum : uint32_t {
     LF_PENDING = 1u,   // this sample has a light query in flight or finished
     LF_DONE = 2u,      // its search has ended

@@ -353,7 +353,7 @@ int rt_upload_scene_from(RtContext* c, const RtScene* s) {
 
 int rt_resize(RtContext* c, int32_t width, int32_t height) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
-    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 27))
         return fail(c, RT_ERR_INVALID_ARGUMENT, "bad image size");
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -373,7 +373,7 @@ int rt_resize(RtContext* c, int32_t width, int32_t height) {
 
 int rt_bind_framebuffer(RtContext* c, int32_t width, int32_t height, void* d_accum, void* d_counts, void* d_bgra) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
-    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28) || !d_accum || !d_counts || !d_bgra)
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 27) || !d_accum || !d_counts || !d_bgra)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "bad framebuffer binding");
     if (((uintptr_t)d_accum & 15u) || ((uintptr_t)d_counts & 3u) || ((uintptr_t)d_bgra & 3u))
         return fail(c, RT_ERR_INVALID_ARGUMENT, "framebuffer pointers must be 16/4/4-byte aligned");
@@ -760,7 +760,7 @@ int rt_render_frames(RtContext* c, const RtCamera* camera, const RtPushConstants
 int rt_render_frame_noalloc(RtContext* c, const RtCamera* camera, const RtPushConstants* pc, const RtParams* params, void* d_accum,
                             void* d_counts, void* d_bgra, int32_t width, int32_t height) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
-    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28) || !d_accum || !d_counts || !d_bgra)
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 27) || !d_accum || !d_counts || !d_bgra)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "bad framebuffer");
     if (((uintptr_t)d_accum & 15u) || ((uintptr_t)d_counts & 3u) || ((uintptr_t)d_bgra & 3u))
         return fail(c, RT_ERR_INVALID_ARGUMENT, "framebuffer pointers must be 16/4/4-byte aligned");

@@ -33,7 +33,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("W,H,strip,n", [(512, 288, (0, 1, 0), 3), (512, 288, (0, 1, 0), 18), (640, 600, (9, 2, 1), 4), (520, 291, (0, 1, 0), 2)])
+@pytest.mark.parametrize("W,H,strip,n", [(512, 288, (0, 1, 0), 3), (512, 288, (0, 1, 0), 18), (512, 288, (0, 1, 0), 35), (640, 600, (9, 2, 1), 4), (520, 291, (0, 1, 0), 2)])
 def test_fused_frames_equal_one_call_each(ctx, W, H, strip, n):
     scene = Scene(capi.RT_SCENE_CORNELL_TEAPOT)
     cam = default_camera(W, H)
@@ -43,13 +43,13 @@ def test_fused_frames_equal_one_call_each(ctx, W, H, strip, n):
     ctx.resize(W, H)
     ctx.render_frames(cam, pcs, params)
     st = ctx.stats()
-    assert st.frames == (n if n <= 16 else n - 16) and st.pipeline == capi.RT_PIPELINE_POOLED  # really one launch (two for 18)
+    assert st.frames == (n if n <= 32 else n - 32) and st.pipeline == capi.RT_PIPELINE_POOLED  # really one launch (two for 35)
     acc, cnt = ctx.read_accum()
     got = (acc, cnt, ctx.read_bgra8())
     assert _same(got, want)
     owned = cnt > 0
     assert owned.any() and (cnt[owned] == n).all()
-    if n <= 16:
+    if n <= 32:
         assert st.rays == want[3]
     # a second call goes on accumulating (no reset), and equals the same frames one by one
     more = [scene.push_constants(0.0, 100 + k, False) for k in range(2)]
@@ -60,7 +60,7 @@ def test_fused_frames_equal_one_call_each(ctx, W, H, strip, n):
     assert _same((acc2, cnt2, bgra2), want2)
 
 
-@pytest.mark.parametrize("W,H,spp,mb,n,rounds", [(512, 288, 1, 0, 16, 3), (1920, 1080, 2, 2, 4, 2), (1000, 500, 1, 1, 16, 2)])
+@pytest.mark.parametrize("W,H,spp,mb,n,rounds", [(512, 288, 1, 0, 16, 3), (1920, 1080, 2, 2, 4, 2), (1000, 500, 1, 1, 16, 2), (512, 288, 1, 0, 32, 2)])
 def test_fused_frames_under_heavy_overlap(ctx, W, H, spp, mb, n, rounds):
     """Short pixels and many frames: frames of the same pixel are in flight at the same time all over the image, so the
     wait of a pixel's end for its block's previous frame (and the L2 as the one place the framebuffer is read
