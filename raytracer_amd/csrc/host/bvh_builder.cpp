@@ -52,8 +52,8 @@ struct BuildPrim {
 // errors grow with the magnitude of the ray's origin and the distance walked, not with the primitive's own
 // coordinates: in position units at most about 2.5e-7 x (|origin| + |box| + distance) <= 1e-6 x S for rays that
 // start inside a scene whose coordinates reach S.  The pad is the same for every primitive, kPadOfScale x max(1, S):
-// five times that bound (a camera further than about 4 S from the origin eats into the margin).  Until round 3 of
-// this build it was 1e-4 x max(1, the primitive's own largest coordinate): up to 2e-3 on the 0.03-wide triangles of
+// five times that bound (a camera further than about 4 S from the origin eats into the margin).  An earlier
+// pad was 1e-4 x max(1, the primitive's own largest coordinate): up to 2e-3 on the 0.03-wide triangles of
 // the 1.07 M-triangle scene, 3 % of whose node visits and 6 % of whose primitive tests were the pad's.  Measured
 // with the pad at 5e-8 of the primitive's coordinate: still no pixel differs from the flat search (tools/edge_ties.py).
 const float kPadOfScale = 5e-6f;

@@ -1,5 +1,5 @@
 """The example hosts on the C ABI (examples/): a plain C99 program and the C++ binding a maintainer
-of the reference application would add (the stub of INTEGRATION.md, compiled).  Without a GPU they
+of the reference application would add (the stub the integration notes print, compiled).  Without a GPU they
 are built and answer their no-argument self-checks; on the GPU the C program's image must be the
 image the Python path renders, and the C++ program must find application-owned scene vectors and
 the library's scene object rendering the same picture."""
@@ -36,7 +36,7 @@ def test_examples_build_against_the_header_and_library():
 
 
 def test_integration_doc_shows_the_compiled_binding():
-    """The HipBackend class printed in INTEGRATION.md is the one in examples/hip_backend.cpp
+    """The HipBackend class printed in the integration notes is the one in examples/hip_backend.cpp
     (same calls in the same order), so the document cannot drift from code that compiles."""
     calls = lambda text: re.findall(r"\brt_[a-z0-9_]+(?=\()", text)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
