@@ -157,7 +157,11 @@ struct PoolSlot {
     RT_DEV void put_light_record(const LightRecord& q) const {
         cold_store(cold + 1, f4(q.normal, q.s_d));
         cold_store(cold + 2, f4(q.vdir, __uint_as_float((q.front_face ? 0x80000000u : 0u) | ((uint32_t)q.light << 16) | (uint32_t)q.mat)));
+#if defined(RT_TAIL_DIAG)
+        cold_store(cold + 3, f4(q.ldir, cold[3].w));  // (the word keeps the pixel's start time)
+#else
         cold_store(cold + 3, f4(q.ldir, 0.0f));
+#endif
     }
     RT_DEV void get_light_record(LightRecord& q) const {
         const float4 n = cold_load(cold + 1), v = cold_load(cold + 2), l = cold_load(cold + 3);
@@ -167,6 +171,10 @@ struct PoolSlot {
         q.mat = (int)(bits & 0xffffu); q.front_face = (bits >> 31) != 0u;
         q.ldir = xyz(l);
     }
+#if defined(RT_TAIL_DIAG)
+    RT_DEV void put_start(uint32_t t) const { ((uint32_t*)(cold + 3))[3] = t; }
+    RT_DEV uint32_t get_start() const { return ((const uint32_t*)(cold + 3))[3]; }
+#endif
     RT_DEV int get_light_hit_id() const { return __float_as_int(cold[3].w); }  // written when the per-pixel hash is on
     RT_DEV uint32_t get_flags() const { return (*(const volatile __attribute__((address_space(3))) uint32_t*)&L.flags[i >> 2] >> (8u * (i & 3u))) & 0xffu; }
     RT_DEV void put_flags(uint32_t f) const { *(volatile __attribute__((address_space(3))) uint8_t*)((uint8_t*)L.flags + i) = (uint8_t)f; }

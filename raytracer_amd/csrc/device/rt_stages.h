@@ -120,7 +120,9 @@ RT_DEV bool shade_item(const DeviceScene& sc, const FrameArgs& fa, const Slot& s
     }
     if (kind == 0) {
         sl.put_flags(flags);
+#if !defined(RT_TAIL_DIAG)
         if (sample == 0u && (fa.flags & 1u) && fa.primary_ids != nullptr) fa.primary_ids[pixel & kPixelIndexMask] = prim_id;
+#endif
     }
     phash = (phash ^ (uint32_t)(prim_id + 1)) * 0x01000193u;
 
@@ -262,6 +264,15 @@ RT_DEV bool end_pixel_item(const FrameArgs& fa, const Slot& sl) {
     ff.bgra[pixel] = resolve_pixel(a, n);
     if ((ff.flags & 2u) && ff.path_hash != nullptr) ff.path_hash[pixel] = phash;
     report_pixel_cost(ff, px, py, (uint32_t)cost);
+#if defined(RT_TAIL_DIAG)
+    // diagnostic build (tools/tail_diag.py): instead of the primary-hit id, when the pixel started and ended (units of
+    // 40.96 us of the constant 100 MHz counter, 12 bits each) and what it cost (path segments, clipped to 255)
+    if (ff.primary_ids != nullptr) {
+        const uint32_t now = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> 12) & 0xfffu;
+        const uint32_t c8 = (uint32_t)cost > 255u ? 255u : (uint32_t)cost;
+        ff.primary_ids[pixel] = (int)((sl.get_start() << 20) | (now << 8) | c8);
+    }
+#endif
     if (batch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached the L2 before the block's count says so
         (void)l2_add(&ff.block_done[block], 1u);
@@ -275,6 +286,9 @@ RT_DEV void start_pixel(const FrameArgs& fa, const Slot& sl, int x, int y, uint3
     const uint32_t frame_count = BATCH ? sl.frame_count_of(frame) : fa.frame_count;
     const uint32_t seed = rng_hash(fa.time_u * 1920u) ^ rng_hash(frame_count) ^ rng_hash((uint32_t)(x + y * 1920));
     sl.put_pix(v3(0.0f), 0.0f);
+#if defined(RT_TAIL_DIAG)
+    sl.put_start((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 12) & 0xfffu);
+#endif
     start_sample(fa, sl, seed, (uint32_t)(y * fa.width + x) | (frame << kPixelFrameShift), 0u, 0u);
 }
 
